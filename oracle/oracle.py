@@ -1,0 +1,222 @@
+"""ctypes binding of the CPU oracle (oracle/libsift_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg as the checker / timed baseline.  The product
+package (sift_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsift_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+CANDIDATE_DTYPE = np.dtype([("oct", "<i4"), ("img", "<i4"), ("i", "<i4"), ("j", "<i4")])
+STATS_FIELDS = ("candidates", "out_of_bounds", "no_convergence", "low_contrast", "det_nonpositive",
+                "edge_like", "singular", "localized", "oriented")
+STATS_DTYPE = np.dtype([(f, "<i8") for f in STATS_FIELDS])
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds)."""
+    src = os.path.join(_HERE, "sift_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libsift_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, ci, dp = C.c_void_p, C.c_int, C.POINTER(C.c_double)
+        L.orc_bgr_to_gray.argtypes = [vp, ci, ci, vp]
+        L.orc_create_gray.restype = vp
+        L.orc_create_gray.argtypes = [vp, ci, ci, ci]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_gen_gaussian_images.argtypes = [vp, ci]
+        L.orc_gen_dog_images.argtypes = [vp]
+        L.orc_gen_scale_space_extrema.argtypes = [vp, ci]
+        L.orc_clean_keypoints.argtypes = [vp]
+        L.orc_get_descriptors.argtypes = [vp, ci]
+        L.orc_exec.argtypes = [vp, ci, ci, dp]
+        L.orc_octaves.argtypes = [vp]
+        L.orc_level_dims.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+        for name in ("orc_onex", "orc_base"):
+            getattr(L, name).restype = vp
+            getattr(L, name).argtypes = [vp]
+        for name in ("orc_gauss", "orc_dog"):
+            getattr(L, name).restype = vp
+            getattr(L, name).argtypes = [vp, ci, ci]
+        L.orc_num_candidates.argtypes = [vp]
+        L.orc_candidates.restype = vp
+        L.orc_candidates.argtypes = [vp]
+        L.orc_stats_table.restype = vp
+        L.orc_stats_table.argtypes = [vp]
+        L.orc_num_keypoints.argtypes = [vp]
+        L.orc_keypoints.restype = vp
+        L.orc_keypoints.argtypes = [vp]
+        L.orc_descriptors.restype = vp
+        L.orc_descriptors.argtypes = [vp]
+        L.orc_get.argtypes = [vp, vp]
+        L.orc_gaussian_kernel.argtypes = [C.c_double, dp]
+        L.orc_knn2_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci]
+        L.orc_knn2_u8.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci]
+        L.orc_min_dist_filter.argtypes = [vp, ci, vp]
+        _lib = L
+    return _lib
+
+
+def _from_ptr(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0 or not ptr:
+        return np.zeros(shape, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
+
+
+def bgr_to_gray(bgr):
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w, _ = bgr.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_bgr_to_gray(bgr.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
+def gaussian_kernel(sigma):
+    buf = (C.c_double * 64)()
+    n = lib().orc_gaussian_kernel(float(sigma), buf)
+    return np.array(buf[:n])
+
+
+class OracleSift:
+    """sift::sift_handler restated on the CPU (sift.hpp:20-118)."""
+
+    def __init__(self, gray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        assert gray.ndim == 2
+        self.h, self.w = gray.shape
+        self._L = lib()
+        self._h = self._L.orc_create_gray(gray.ctypes.data, self.w, self.h, self.w)
+        self.timings = None
+
+    def close(self):
+        if self._h:
+            self._L.orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # the five TIMEIT stages of exec()
+    def gen_gaussian_images(self, blur_threads=1):
+        self._L.orc_gen_gaussian_images(self._h, blur_threads)
+
+    def gen_dog_images(self):
+        self._L.orc_gen_dog_images(self._h)
+
+    def gen_scale_space_extrema(self, threads=1):
+        self._L.orc_gen_scale_space_extrema(self._h, threads)
+
+    def clean_keypoints(self):
+        self._L.orc_clean_keypoints(self._h)
+
+    def get_descriptors(self, threads=1):
+        self._L.orc_get_descriptors(self._h, threads)
+
+    def exec(self, threads=1, blur_threads=1):
+        t = (C.c_double * 5)()
+        self._L.orc_exec(self._h, threads, blur_threads, t)
+        self.timings = dict(zip(
+            ("gen_gaussian_images", "gen_dog_images", "gen_scale_space_extrema", "clean_keypoints",
+             "get_descriptors"), list(t)))
+        return self
+
+    @property
+    def octaves(self):
+        return self._L.orc_octaves(self._h)
+
+    def level_dims(self, oct):
+        w, h = C.c_int(), C.c_int()
+        self._L.orc_level_dims(self._h, oct, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def onex(self):
+        return _from_ptr(self._L.orc_onex(self._h), (self.h, self.w), np.float64)
+
+    def base(self):
+        return _from_ptr(self._L.orc_base(self._h), (2 * self.h, 2 * self.w), np.float64)
+
+    def gauss(self, oct, lvl):
+        w, h = self.level_dims(oct)
+        return _from_ptr(self._L.orc_gauss(self._h, oct, lvl), (h, w), np.float64)
+
+    def dog(self, oct, lvl):
+        w, h = self.level_dims(oct)
+        return _from_ptr(self._L.orc_dog(self._h, oct, lvl), (h, w), np.float64)
+
+    def candidates(self):
+        n = self._L.orc_num_candidates(self._h)
+        return _from_ptr(self._L.orc_candidates(self._h), (n,), CANDIDATE_DTYPE)
+
+    def stats(self):
+        return _from_ptr(self._L.orc_stats_table(self._h), (self.octaves, 3), STATS_DTYPE)
+
+    def keypoints(self):
+        n = self._L.orc_num_keypoints(self._h)
+        return _from_ptr(self._L.orc_keypoints(self._h), (n,), KEYPOINT_DTYPE)
+
+    def descriptors(self):
+        n = self._L.orc_num_keypoints(self._h)
+        return _from_ptr(self._L.orc_descriptors(self._h), (n, 128), np.float64)
+
+    def get(self):
+        n = self._L.orc_num_keypoints(self._h)
+        out = np.empty((n, 128), np.float32)
+        if n:
+            self._L.orc_get(self._h, out.ctypes.data)
+        return out
+
+
+def knn2_f32(q, t, threads=1):
+    q = np.ascontiguousarray(q, np.float32)
+    t = np.ascontiguousarray(t, np.float32)
+    nq, dim = q.shape
+    nt = t.shape[0]
+    i1 = np.empty(nq, np.int32); i2 = np.empty(nq, np.int32)
+    d1 = np.empty(nq, np.float32); d2 = np.empty(nq, np.float32)
+    acc = np.empty(nq, np.uint8)
+    lib().orc_knn2_f32(q.ctypes.data, nq, t.ctypes.data, nt, dim, i1.ctypes.data, d1.ctypes.data,
+                       i2.ctypes.data, d2.ctypes.data, acc.ctypes.data, threads)
+    return i1, d1, i2, d2, acc
+
+
+def knn2_u8(q, t, threads=1):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    nq, dim = q.shape
+    nt = t.shape[0]
+    i1 = np.empty(nq, np.int32); i2 = np.empty(nq, np.int32)
+    d1 = np.empty(nq, np.int32); d2 = np.empty(nq, np.int32)
+    acc = np.empty(nq, np.uint8)
+    lib().orc_knn2_u8(q.ctypes.data, nq, t.ctypes.data, nt, dim, i1.ctypes.data, d1.ctypes.data,
+                      i2.ctypes.data, d2.ctypes.data, acc.ctypes.data, threads)
+    return i1, d1, i2, d2, acc
+
+
+def min_dist_filter(dist):
+    dist = np.ascontiguousarray(dist, np.float32)
+    good = np.empty(len(dist), np.int32)
+    n = lib().orc_min_dist_filter(dist.ctypes.data, len(dist), good.ctypes.data)
+    return good[:n].copy()
