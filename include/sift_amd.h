@@ -1,0 +1,192 @@
+/*
+ * sift_amd.h -- C ABI of the MI355X (gfx950) SIFT engine.
+ *
+ * The reference (kannavkm/SIFT) has no FFI layer; its seam is the C++ class
+ * sift::sift_handler (src/sift.hpp:20-118) used by src/main.cpp.  This header is
+ * the boundary a binding of that class talks to: plain pointers and sizes, no
+ * C++/torch types.  Each entry point names the reference interface it
+ * replaces.  All functions return 0 on success and a negative SIFT_ERR_* code
+ * on failure; sift_last_error() gives the message of the calling thread's last
+ * failure.  Nothing throws.
+ *
+ * Threading: a context (and every batch created from it) is bound to one GPU
+ * and must be used from one thread at a time; distinct contexts are
+ * independent.
+ */
+#ifndef SIFT_AMD_H
+#define SIFT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFT_OK 0
+#define SIFT_ERR_INVALID (-1)  /* bad argument */
+#define SIFT_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define SIFT_ERR_OVERFLOW (-3) /* a per-frame candidate/keypoint list exceeded its capacity */
+#define SIFT_ERR_NOT_INTEGRAL (-4) /* float descriptors given to the matcher are not integers in [0,127] */
+
+#define SIFT_DESCRIPTOR_DIM 128
+
+/* Same field order and widths as cv::KeyPoint as the reference fills it
+ * (sift.cpp:375-382, :443): pt.x, pt.y, size, angle, response are float32,
+ * octave = oct + 256*layer + 65536*round((offset+0.5)*255), class_id = -1. */
+typedef struct sift_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} sift_keypoint;
+
+typedef struct sift_ctx sift_ctx;     /* one per GPU */
+typedef struct sift_batch sift_batch; /* pyramid workspace for up to max_frames same-sized frames */
+
+/* Per-frame outcome of sift_batch_run. */
+typedef struct sift_frame_counts {
+    int32_t candidates; /* pixels passing is_pixel_extremum (sift.cpp:264-281) */
+    int32_t oriented;   /* keypoints before clean_keypoints (sift.cpp:183-197) */
+    int32_t keypoints;  /* keypoints after clean_keypoints (sift.cpp:202-225) */
+    int32_t overflow;   /* non-zero when a list exceeded its capacity; results of this frame are incomplete */
+} sift_frame_counts;
+
+/* Result of the single-image convenience call; buffers are owned by the
+ * library and released by sift_result_free. */
+typedef struct sift_result {
+    int32_t n;                /* keypoints.size() */
+    int32_t octaves;          /* sift_handler::octaves (sift.hpp:91) */
+    sift_keypoint *keypoints; /* sift_handler::keypoints (sift.hpp:93), sorted as clean_keypoints leaves them */
+    double *descriptors;      /* sift_handler::descriptors (sift.hpp:94): n x 128 integer-valued doubles */
+    sift_frame_counts counts;
+} sift_result;
+
+const char *sift_last_error(void);
+int sift_device_count(int *count);
+
+/* ---- context ----------------------------------------------------------- */
+int sift_ctx_create(int device, sift_ctx **out);
+int sift_ctx_destroy(sift_ctx *ctx);
+/* The HIP stream (hipStream_t) every call of this context enqueues on. */
+int sift_ctx_stream(sift_ctx *ctx, void **stream);
+int sift_ctx_synchronize(sift_ctx *ctx);
+
+/* ---- geometry helpers (host only) ---------------------------------------- */
+/* octaves = round(log2(min(w,h))) on the input size (sift.cpp:36). */
+int sift_num_octaves(int w, int h);
+/* Size of pyramid octave `oct` for a w x h input: 2w x 2h at octave 0
+ * (sift.cpp:40), then nearest-neighbour halving with cvRound sizes
+ * (sift.cpp:153). */
+int sift_octave_dims(int w, int h, int oct, int *ow, int *oh);
+
+/* ---- single image: constructor + exec() + get() ------------------------- */
+/* Replaces sift_handler(name, Mat&&) + exec() (sift.hpp:23,25) for one 8-bit
+ * image held in host memory.  sift_extract_bgr8 starts at cvtColor(BGR2GRAY)
+ * (sift.cpp:29); sift_extract_gray8 starts after it.  stride is in bytes. */
+int sift_extract_gray8(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, sift_result *out);
+int sift_extract_bgr8(sift_ctx *ctx, const uint8_t *bgr, int w, int h, size_t stride, sift_result *out);
+int sift_result_free(sift_result *r);
+/* get() (sift.hpp:27, sift.cpp:103-112): n x 128 float32 copy of the descriptors. */
+int sift_result_get_f32(const sift_result *r, float *out);
+
+/* ---- batch of frames resident in device memory --------------------------- */
+/* Allocates frame, pyramid, candidate and keypoint buffers for up to
+ * max_frames frames of w x h.  max_keypoints_per_frame <= 0 selects a default
+ * derived from the frame size. */
+int sift_batch_create(sift_ctx *ctx, int w, int h, int max_frames, int max_keypoints_per_frame, sift_batch **out);
+int sift_batch_destroy(sift_batch *b);
+/* Device pointer of the 8-bit gray frame buffer, [max_frames][h][w], for
+ * callers that fill frames on the GPU themselves. */
+int sift_batch_frames_device_ptr(sift_batch *b, void **dptr);
+/* Copy one host frame into slot `frame` (asynchronous on the context stream). */
+int sift_batch_upload_gray8(sift_batch *b, int frame, const uint8_t *gray, size_t stride);
+int sift_batch_upload_bgr8(sift_batch *b, int frame, const uint8_t *bgr, size_t stride);
+/* Enqueue the whole of exec() (sift.cpp:67-98: gen_gaussian_images,
+ * gen_dog_images, gen_scale_space_extrema, clean_keypoints, get_descriptors)
+ * for frames [0, n_frames) on the context stream.  Asynchronous. */
+int sift_batch_run(sift_batch *b, int n_frames);
+/* Wait for the stream, then report per-frame counts.  Returns
+ * SIFT_ERR_OVERFLOW if any frame overflowed (counts are still filled). */
+int sift_batch_counts(sift_batch *b, int n_frames, sift_frame_counts *counts);
+/* Copy frame results to the host.  keypoints/desc_u8/desc_f64 may be NULL;
+ * each must hold `capacity` keypoints (x128 for descriptors).  *n receives the
+ * frame's keypoint count. */
+int sift_batch_download(sift_batch *b, int frame, int capacity, sift_keypoint *keypoints, uint8_t *desc_u8,
+                        double *desc_f64, int32_t *n);
+/* Device pointers of a frame's final keypoints (32-byte records whose first 28
+ * bytes are a sift_keypoint) and 128-byte descriptors, valid until the next run. */
+int sift_batch_result_device_ptrs(sift_batch *b, int frame, void **keypoints, void **desc_u8);
+
+/* Parity/debug accessors (host copies of intermediate images and lists). */
+#define SIFT_LEVEL_GAUSS 0 /* gauss_images[oct][lvl], lvl 0..5 (sift.hpp:115) */
+#define SIFT_LEVEL_DOG 1   /* images[oct][lvl], lvl 0..4 (sift.hpp:114) */
+int sift_batch_get_level(sift_batch *b, int frame, int oct, int lvl, int kind, double *out);
+/* Candidates as (oct, img, i, j) int32 quadruples in unspecified order. */
+int sift_batch_get_candidates(sift_batch *b, int frame, int capacity, int32_t *quads, int32_t *n);
+/* Keypoints before clean_keypoints, unspecified order. */
+int sift_batch_get_oriented(sift_batch *b, int frame, int capacity, sift_keypoint *kps, int32_t *n);
+
+/* Per-kernel device time of one run, measured with HIP events on the context
+ * stream around every launch (serialises the run; use for profiling only). */
+#define SIFT_STAGE_BASE 0       /* gray -> 2x upsample -> base blur (sift.cpp:40-42) */
+#define SIFT_STAGE_BLUR_DOG 1   /* GaussianBlur levels 1..5 + subtract + next-octave resize (sift.cpp:150-153,173) */
+#define SIFT_STAGE_EXTREMA 2    /* 3x3x3 scan (sift.cpp:227-281) */
+#define SIFT_STAGE_LOCALIZE 3   /* localize_extrema + get_keypoint_orientations (sift.cpp:312-448) */
+#define SIFT_STAGE_CLEAN 4      /* clean_keypoints (sift.cpp:202-225) */
+#define SIFT_STAGE_DESCRIPTOR 5 /* get_descriptors (sift.cpp:450-584) */
+#define SIFT_STAGE_COUNT 6
+typedef struct sift_stage_times {
+    double ms[SIFT_STAGE_COUNT];    /* summed kernel time per stage */
+    int32_t launches[SIFT_STAGE_COUNT];
+} sift_stage_times;
+int sift_batch_run_profiled(sift_batch *b, int n_frames, sift_stage_times *times);
+
+/* ---- matcher: exact brute-force top-2 + ratio test ------------------------ */
+/* Replaces FlannBasedMatcher::match / knnMatch(k=2) at main.cpp:48-51,75 and
+ * the ratio filter at main.cpp:186-198 with an exact search: for every query
+ * the two nearest train descriptors under squared L2, ordered by (distance,
+ * train index). */
+typedef struct sift_knn2 {
+    int32_t d1; /* squared distance to the nearest train descriptor (INT32_MAX if none) */
+    int32_t i1; /* its index (-1 if none) */
+    int32_t d2; /* second nearest */
+    int32_t i2;
+} sift_knn2;
+
+/* Host buffers, byte descriptors with values in [0,127]; [n][128] row-major.
+ * accept[i] = sqrtf(d1) < 0.7f*sqrtf(d2) (main.cpp:190,194); accept may be NULL. */
+int sift_knn2_u8(sift_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, sift_knn2 *out, uint8_t *accept);
+/* Same for float descriptors as get() returns them; values must be integers in
+ * [0,127] (they always are for this engine: sift.cpp:566-573), otherwise
+ * SIFT_ERR_NOT_INTEGRAL. */
+int sift_knn2_f32(sift_ctx *ctx, const float *q, int nq, const float *t, int nt, sift_knn2 *out, uint8_t *accept);
+/* Device-resident operands (asynchronous on the context stream).  d_q and d_t
+ * are device pointers to [n][128] bytes; d_out receives nq sift_knn2 records
+ * whose indices are offset by train_index_base (for a train shard). */
+int sift_knn2_device(sift_ctx *ctx, const void *d_q, int nq, const void *d_t, int nt, int train_index_base,
+                     void *d_out);
+/* Merge `nparts` partial results per query (d_parts laid out [nparts][nq]) into
+ * d_out[nq] ordered by (distance, index), and apply the ratio test into
+ * d_accept[nq] (may be NULL).  Device pointers, asynchronous. */
+int sift_knn2_merge_device(sift_ctx *ctx, const void *d_parts, int nparts, int nq, void *d_out, void *d_accept);
+/* Bytes of scratch sift_knn2_device needs (train norms); allocated once per context on demand. */
+
+/* The live filter of main.cpp:77-91 on 1-NN results: min_dist starts at 100,
+ * a query is good when sqrtf(d1) < 3*min_dist.  Host only.  Returns the number
+ * of good matches through *n_good and their query indices in good_idx. */
+int sift_match_min_dist_filter(const sift_knn2 *knn, int nq, int32_t *good_idx, int32_t *n_good);
+
+/* ---- synthetic inputs (host) ---------------------------------------------- */
+/* Dead-leaves frame generator: splitmix64 seeded with
+ * seed*0x9E3779B97F4A7C15 + frame_index; w*h/128 discs painted over a 128-gray
+ * canvas in draw order.  Integer-only, so identical everywhere. */
+int sift_synth_dead_leaves(uint64_t seed, uint64_t frame_index, int w, int h, uint8_t *gray);
+/* SIFT-like byte descriptors in [0,102]: n rows of 128. */
+int sift_synth_descriptors(uint64_t seed, int64_t n, uint8_t *out);
+/* Queries: for even i a noisy copy (noise in [-2,2], clamped to [0,102]) of a
+ * pseudo-random train row, for odd i an independent descriptor. */
+int sift_synth_queries(uint64_t seed, const uint8_t *train, int64_t nt, int64_t nq, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

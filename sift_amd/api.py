@@ -1,0 +1,326 @@
+"""ctypes binding of the C ABI in include/sift_amd.h (sift_amd/libsift_amd.so).
+
+This module is plumbing: every compute call goes straight to the HIP library.
+There is no CPU fallback; if the library is missing or no GPU is present the
+calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsift_amd.so")
+
+SIFT_OK = 0
+SIFT_ERR_INVALID = -1
+SIFT_ERR_HIP = -2
+SIFT_ERR_OVERFLOW = -3
+SIFT_ERR_NOT_INTEGRAL = -4
+
+LEVEL_GAUSS = 0
+LEVEL_DOG = 1
+
+STAGE_NAMES = ("base", "blur_dog", "extrema", "localize_orient", "clean", "descriptor")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+KNN2_DTYPE = np.dtype([("d1", "<i4"), ("i1", "<i4"), ("d2", "<i4"), ("i2", "<i4")])
+COUNTS_DTYPE = np.dtype([("candidates", "<i4"), ("oriented", "<i4"), ("keypoints", "<i4"), ("overflow", "<i4")])
+
+# every symbol include/sift_amd.h declares
+EXPORTED_SYMBOLS = (
+    "sift_last_error", "sift_device_count", "sift_ctx_create", "sift_ctx_destroy", "sift_ctx_stream",
+    "sift_ctx_synchronize", "sift_num_octaves", "sift_octave_dims", "sift_extract_gray8", "sift_extract_bgr8",
+    "sift_result_free", "sift_result_get_f32", "sift_batch_create", "sift_batch_destroy",
+    "sift_batch_frames_device_ptr", "sift_batch_upload_gray8", "sift_batch_upload_bgr8", "sift_batch_run",
+    "sift_batch_counts", "sift_batch_download", "sift_batch_result_device_ptrs", "sift_batch_get_level",
+    "sift_batch_get_candidates", "sift_batch_get_oriented", "sift_batch_run_profiled", "sift_knn2_u8",
+    "sift_knn2_f32", "sift_knn2_device", "sift_knn2_merge_device", "sift_match_min_dist_filter",
+    "sift_synth_dead_leaves", "sift_synth_descriptors", "sift_synth_queries",
+)
+
+
+class SiftError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("sift_amd error %d: %s" % (code, message))
+        self.code = code
+
+
+class _FrameCounts(C.Structure):
+    _fields_ = [("candidates", C.c_int32), ("oriented", C.c_int32), ("keypoints", C.c_int32),
+                ("overflow", C.c_int32)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("n", C.c_int32), ("octaves", C.c_int32), ("keypoints", C.c_void_p),
+                ("descriptors", C.c_void_p), ("counts", _FrameCounts)]
+
+
+class _StageTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int32 * 6)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libsift_amd.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SiftError(SIFT_ERR_INVALID, "%s is missing: build it with `make -C sift_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ci, sz, u64, i64 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_int64
+    pvp = C.POINTER(C.c_void_p)
+    L.sift_last_error.restype = C.c_char_p
+    L.sift_last_error.argtypes = []
+    L.sift_device_count.argtypes = [C.POINTER(ci)]
+    L.sift_ctx_create.argtypes = [ci, pvp]
+    L.sift_ctx_destroy.argtypes = [vp]
+    L.sift_ctx_stream.argtypes = [vp, pvp]
+    L.sift_ctx_synchronize.argtypes = [vp]
+    L.sift_num_octaves.argtypes = [ci, ci]
+    L.sift_octave_dims.argtypes = [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.sift_extract_gray8.argtypes = [vp, vp, ci, ci, sz, C.POINTER(_Result)]
+    L.sift_extract_bgr8.argtypes = [vp, vp, ci, ci, sz, C.POINTER(_Result)]
+    L.sift_result_free.argtypes = [C.POINTER(_Result)]
+    L.sift_result_get_f32.argtypes = [C.POINTER(_Result), vp]
+    L.sift_batch_create.argtypes = [vp, ci, ci, ci, ci, pvp]
+    L.sift_batch_destroy.argtypes = [vp]
+    L.sift_batch_frames_device_ptr.argtypes = [vp, pvp]
+    L.sift_batch_upload_gray8.argtypes = [vp, ci, vp, sz]
+    L.sift_batch_upload_bgr8.argtypes = [vp, ci, vp, sz]
+    L.sift_batch_run.argtypes = [vp, ci]
+    L.sift_batch_counts.argtypes = [vp, ci, vp]
+    L.sift_batch_download.argtypes = [vp, ci, ci, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.sift_batch_result_device_ptrs.argtypes = [vp, ci, pvp, pvp]
+    L.sift_batch_get_level.argtypes = [vp, ci, ci, ci, ci, vp]
+    L.sift_batch_get_candidates.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_int32)]
+    L.sift_batch_get_oriented.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_int32)]
+    L.sift_batch_run_profiled.argtypes = [vp, ci, C.POINTER(_StageTimes)]
+    L.sift_knn2_u8.argtypes = [vp, vp, ci, vp, ci, vp, vp]
+    L.sift_knn2_f32.argtypes = [vp, vp, ci, vp, ci, vp, vp]
+    L.sift_knn2_device.argtypes = [vp, vp, ci, vp, ci, ci, vp]
+    L.sift_knn2_merge_device.argtypes = [vp, vp, ci, ci, vp, vp]
+    L.sift_match_min_dist_filter.argtypes = [vp, ci, vp, C.POINTER(C.c_int32)]
+    L.sift_synth_dead_leaves.argtypes = [u64, u64, ci, ci, vp]
+    L.sift_synth_descriptors.argtypes = [u64, i64, vp]
+    L.sift_synth_queries.argtypes = [u64, vp, i64, i64, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != SIFT_OK:
+        raise SiftError(rc, lib().sift_last_error().decode("utf-8", "replace"))
+
+
+# ---- host-only helpers ------------------------------------------------------
+
+def num_octaves(w, h):
+    return lib().sift_num_octaves(w, h)
+
+
+def octave_dims(w, h, oct):
+    ow, oh = C.c_int(), C.c_int()
+    _check(lib().sift_octave_dims(w, h, oct, C.byref(ow), C.byref(oh)))
+    return ow.value, oh.value
+
+
+def synth_dead_leaves(seed, frame_index, w, h):
+    out = np.empty((h, w), np.uint8)
+    _check(lib().sift_synth_dead_leaves(seed, frame_index, w, h, out.ctypes.data))
+    return out
+
+
+def synth_descriptors(seed, n):
+    out = np.empty((n, 128), np.uint8)
+    _check(lib().sift_synth_descriptors(seed, n, out.ctypes.data))
+    return out
+
+
+def synth_queries(seed, train, nq):
+    train = np.ascontiguousarray(train, np.uint8)
+    out = np.empty((nq, 128), np.uint8)
+    _check(lib().sift_synth_queries(seed, train.ctypes.data, train.shape[0], nq, out.ctypes.data))
+    return out
+
+
+def min_dist_filter(knn):
+    knn = np.ascontiguousarray(knn, KNN2_DTYPE)
+    good = np.empty(len(knn), np.int32)
+    n = C.c_int32()
+    _check(lib().sift_match_min_dist_filter(knn.ctypes.data, len(knn), good.ctypes.data, C.byref(n)))
+    return good[: n.value].copy()
+
+
+# ---- GPU objects ----------------------------------------------------------
+
+class Context:
+    """One per GPU: owns the HIP stream every call enqueues on."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().sift_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().sift_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().sift_ctx_synchronize(self._h))
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        _check(lib().sift_ctx_stream(self._h, C.byref(s)))
+        return s.value
+
+    # sift_handler(name, Mat&&) + exec() + get()
+    def extract(self, image):
+        """image: HxW uint8 gray or HxWx3 uint8 BGR.  Returns (keypoints, descriptors float64 Nx128, info)."""
+        image = np.ascontiguousarray(image, np.uint8)
+        res = _Result()
+        if image.ndim == 2:
+            h, w = image.shape
+            _check(lib().sift_extract_gray8(self._h, image.ctypes.data, w, h, image.strides[0], C.byref(res)))
+        elif image.ndim == 3 and image.shape[2] == 3:
+            h, w, _ = image.shape
+            _check(lib().sift_extract_bgr8(self._h, image.ctypes.data, w, h, image.strides[0], C.byref(res)))
+        else:
+            raise SiftError(SIFT_ERR_INVALID, "image must be HxW or HxWx3 uint8")
+        try:
+            n = res.n
+            kps = np.zeros(n, KEYPOINT_DTYPE)
+            desc = np.zeros((n, 128), np.float64)
+            if n:
+                C.memmove(kps.ctypes.data, res.keypoints, n * KEYPOINT_DTYPE.itemsize)
+                C.memmove(desc.ctypes.data, res.descriptors, n * 128 * 8)
+            info = {"octaves": res.octaves, "candidates": res.counts.candidates,
+                    "oriented": res.counts.oriented, "keypoints": res.counts.keypoints}
+        finally:
+            lib().sift_result_free(C.byref(res))
+        return kps, desc, info
+
+    def batch(self, w, h, max_frames, max_keypoints_per_frame=0):
+        return Batch(self, w, h, max_frames, max_keypoints_per_frame)
+
+    # matcher
+    def knn2(self, q, t):
+        """Exact top-2 + ratio test.  q, t: Nx128 uint8 (values <= 127) or float32 integer-valued."""
+        q = np.ascontiguousarray(q)
+        t = np.ascontiguousarray(t)
+        nq, nt = q.shape[0], t.shape[0]
+        out = np.zeros(nq, KNN2_DTYPE)
+        acc = np.zeros(nq, np.uint8)
+        if q.dtype == np.uint8 and t.dtype == np.uint8:
+            _check(lib().sift_knn2_u8(self._h, q.ctypes.data, nq, t.ctypes.data, nt, out.ctypes.data, acc.ctypes.data))
+        else:
+            q = np.ascontiguousarray(q, np.float32)
+            t = np.ascontiguousarray(t, np.float32)
+            _check(lib().sift_knn2_f32(self._h, q.ctypes.data, nq, t.ctypes.data, nt, out.ctypes.data, acc.ctypes.data))
+        return out, acc
+
+    def knn2_device(self, d_q, nq, d_t, nt, train_base, d_out):
+        _check(lib().sift_knn2_device(self._h, d_q, nq, d_t, nt, train_base, d_out))
+
+    def knn2_merge_device(self, d_parts, nparts, nq, d_out, d_accept):
+        _check(lib().sift_knn2_merge_device(self._h, d_parts, nparts, nq, d_out, d_accept))
+
+
+class Batch:
+    """Pyramid workspace for up to max_frames same-sized frames resident in HBM."""
+
+    def __init__(self, ctx, w, h, max_frames, max_keypoints_per_frame=0):
+        self.ctx = ctx
+        self.w, self.h, self.max_frames = w, h, max_frames
+        self._h = C.c_void_p()
+        _check(lib().sift_batch_create(ctx._h, w, h, max_frames, max_keypoints_per_frame, C.byref(self._h)))
+        self.octaves = num_octaves(w, h)
+
+    def close(self):
+        if self._h:
+            lib().sift_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def frames_device_ptr(self):
+        p = C.c_void_p()
+        _check(lib().sift_batch_frames_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def upload(self, frame, image):
+        image = np.ascontiguousarray(image, np.uint8)
+        if image.ndim == 2:
+            assert image.shape == (self.h, self.w)
+            _check(lib().sift_batch_upload_gray8(self._h, frame, image.ctypes.data, image.strides[0]))
+        else:
+            assert image.shape == (self.h, self.w, 3)
+            _check(lib().sift_batch_upload_bgr8(self._h, frame, image.ctypes.data, image.strides[0]))
+
+    def run(self, n_frames):
+        _check(lib().sift_batch_run(self._h, n_frames))
+
+    def run_profiled(self, n_frames):
+        t = _StageTimes()
+        _check(lib().sift_batch_run_profiled(self._h, n_frames, C.byref(t)))
+        return {STAGE_NAMES[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(6)}
+
+    def counts(self, n_frames):
+        out = np.zeros(n_frames, COUNTS_DTYPE)
+        _check(lib().sift_batch_counts(self._h, n_frames, out.ctypes.data))
+        return out
+
+    def download(self, frame):
+        n = C.c_int32()
+        cnt = self.counts(frame + 1)[frame]
+        cap = int(cnt["keypoints"])
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 128), np.uint8)
+        _check(lib().sift_batch_download(self._h, frame, cap, kps.ctypes.data, desc.ctypes.data, None, C.byref(n)))
+        return kps[: n.value], desc[: n.value]
+
+    def result_device_ptrs(self, frame):
+        k, d = C.c_void_p(), C.c_void_p()
+        _check(lib().sift_batch_result_device_ptrs(self._h, frame, C.byref(k), C.byref(d)))
+        return k.value, d.value
+
+    def level(self, frame, oct, lvl, kind=LEVEL_GAUSS):
+        ow, oh = octave_dims(self.w, self.h, oct)
+        out = np.empty((oh, ow), np.float64)
+        _check(lib().sift_batch_get_level(self._h, frame, oct, lvl, kind, out.ctypes.data))
+        return out
+
+    def candidates(self, frame):
+        n = C.c_int32()
+        _check(lib().sift_batch_get_candidates(self._h, frame, 0, None, C.byref(n)))
+        out = np.zeros((n.value, 4), np.int32)
+        if n.value:
+            _check(lib().sift_batch_get_candidates(self._h, frame, n.value, out.ctypes.data, C.byref(n)))
+        return out
+
+    def oriented(self, frame):
+        n = C.c_int32()
+        _check(lib().sift_batch_get_oriented(self._h, frame, 0, None, C.byref(n)))
+        out = np.zeros(n.value, KEYPOINT_DTYPE)
+        if n.value:
+            _check(lib().sift_batch_get_oriented(self._h, frame, n.value, out.ctypes.data, C.byref(n)))
+        return out

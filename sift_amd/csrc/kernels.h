@@ -1,0 +1,36 @@
+// Host-side launchers of the HIP kernels (internal to the library).
+#pragma once
+
+#include "common.h"
+
+namespace sa {
+
+// kernels_pyramid.hip
+int blur_radius_supported(int r);
+int pyramid_init_attributes();
+void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframes, const Pyramid &p, const Taps &taps,
+                 int ntaps);
+void launch_blur_dog(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps);
+void launch_bgr_to_gray(hipStream_t st, const uint8_t *bgr, uint8_t *gray, size_t npix);
+
+// kernels_extrema.hip
+void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
+                    FrameCounters *counters);
+void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
+                            DevKeypoint *oriented, int kp_cap, FrameCounters *counters, int32_t *cursors);
+
+// kernels_keypoints.hip
+void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevKeypoint *sorted, DevKeypoint *final_kp,
+                  uint8_t *flags, int kp_cap, FrameCounters *counters);
+
+// kernels_descriptor.hip
+void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
+                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc);
+
+// kernels_knn.hip
+size_t knn_scratch_bytes(int nq, int nt);
+void launch_knn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int train_base, sift_knn2 *out,
+                 void *scratch);
+void launch_knn2_merge(hipStream_t st, const sift_knn2 *parts, int nparts, int nq, sift_knn2 *out, uint8_t *accept);
+
+}  // namespace sa

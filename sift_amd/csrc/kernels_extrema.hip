@@ -1,0 +1,337 @@
+// Scale-space extrema: 3x3x3 scan with wave-ballot compaction, then per
+// candidate sub-pixel localisation and orientation assignment.
+//
+// Replaces scale_space_extrema_parallel::operator() and its helpers
+// (sift.cpp:227-448).  Floating-point operations are written in the order of a
+// scalar evaluation of those functions and contraction is off for this file,
+// so localisation is bit-reproducible against a CPU evaluation; the
+// orientation histogram is summed per lane and combined in a fixed tree order,
+// so it is deterministic run to run.
+#include "common.h"
+#include "kernels.h"
+
+namespace sa {
+
+namespace {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Reserve `count(flag)` consecutive slots of a per-frame list for the lanes of
+// this wave whose flag is set; returns the lane's slot or -1.
+__device__ __forceinline__ int wave_append(bool flag, int32_t *counter) {
+    const unsigned long long mask = __ballot(flag);
+    if (mask == 0) return -1;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    const int rank = __popcll(mask & ((1ull << lane_id()) - 1ull));
+    return flag ? base + rank : -1;
+}
+
+// is_pixel_extremum (sift.cpp:264-281) for the three scanned layers of one pixel.
+__global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
+                                                  FrameCounters *__restrict__ counters) {
+    const int w = p.w[oct], h = p.h[oct];
+    const int f = blockIdx.z;
+    const int j = BORDER + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = BORDER + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool inside = (j < w - BORDER) && (i < h - BORDER);
+    const size_t plane = (size_t)w * h;
+    const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
+    const double threshold = floor(0.5 * CONTRAST_THRESHOLD / SCALES * 255);  // sift.cpp:266
+    for (int img = 1; img <= SCALES; img++) {
+        bool is_ext = false;
+        if (inside) {
+            const double *Dc = D + (size_t)img * plane + (size_t)i * w + j;
+            const double c = *Dc;
+            if (fabs(c) > threshold) {  // sift.cpp:268
+                bool is_max = true, is_min = true;
+#pragma unroll
+                for (int k = -1; k <= 1; k++) {
+                    const double *Dk = Dc + (ptrdiff_t)k * (ptrdiff_t)plane;
+#pragma unroll
+                    for (int a = -1; a <= 1; a++)
+#pragma unroll
+                        for (int b = -1; b <= 1; b++) {
+                            const double v = Dk[a * w + b];
+                            is_max &= c >= v;
+                            is_min &= c <= v;
+                        }
+                }
+                is_ext = ((c < 0) & is_min) | ((c > 0) & is_max);  // sift.cpp:280
+            }
+        }
+        const int slot = wave_append(is_ext, &counters[f].candidates);
+        if (slot >= 0) {
+            if (slot < cand_cap) {
+                Candidate cd = {oct, img, i, j};
+                cand[(size_t)f * cand_cap + slot] = cd;
+            } else {
+                counters[f].overflow = 1;
+            }
+        }
+    }
+}
+
+// hal::LU64f (eps = DBL_EPSILON*100): in-place LU with partial pivoting, one rhs.
+__device__ __forceinline__ bool lu_solve3(double A[3][3], double b[3]) {
+    const double eps = 2.220446049250313e-16 * 100;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        int k = i;
+        double best = fabs(A[i][i]);
+#pragma unroll
+        for (int j = i + 1; j < 3; j++) {
+            const double a = fabs(A[j][i]);
+            if (a > best) {
+                best = a;
+                k = j;
+            }
+        }
+        if (best < eps) return false;
+        if (k != i) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (j >= i) {
+                    // k is 1 or 2 here; select without dynamic register indexing
+                    double ai = A[i][j];
+                    double ak = (k == 1) ? A[1][j] : A[2][j];
+                    A[i][j] = ak;
+                    if (k == 1) A[1][j] = ai; else A[2][j] = ai;
+                }
+            }
+            double bi = b[i];
+            double bk = (k == 1) ? b[1] : b[2];
+            b[i] = bk;
+            if (k == 1) b[1] = bi; else b[2] = bi;
+        }
+        const double d = -1 / A[i][i];
+#pragma unroll
+        for (int j = i + 1; j < 3; j++) {
+            const double alpha = A[j][i] * d;
+#pragma unroll
+            for (int kk = i + 1; kk < 3; kk++) A[j][kk] += alpha * A[i][kk];
+            b[j] += alpha * b[i];
+        }
+    }
+#pragma unroll
+    for (int i = 2; i >= 0; i--) {
+        double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 3; k++) s -= A[i][k] * b[k];
+        b[i] = s / A[i][i];
+    }
+    return true;
+}
+
+// cv::solve(H, g, x, DECOMP_NORMAL) (sift.cpp:332): N = H^T H, r = H^T g, LU.
+__device__ __forceinline__ bool solve_normal3(const double H[3][3], const double g[3], double x[3]) {
+    double N[3][3], r[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += H[k][i] * H[k][j];
+            N[i][j] = s;
+            N[j][i] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) s += H[k][i] * g[k];
+        r[i] = s;
+    }
+    if (!lu_solve3(N, r)) return false;
+    x[0] = r[0];
+    x[1] = r[1];
+    x[2] = r[2];
+    return true;
+}
+
+// localize_extrema (sift.cpp:312-387).  Returns the layer, 0 if the solve
+// failed, -1 if rejected.
+__device__ int localize(const Pyramid &p, int f, int oct, int img, int i, int j, DevKeypoint &kpt) {
+    const int w = p.w[oct], h = p.h[oct];
+    const size_t plane = (size_t)w * h;
+    const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
+    double cube[3][3][3], grad[3], hess[3][3], res[3];
+    int attempt;
+    for (attempt = 0; attempt < 5; attempt++) {
+        const double inv = 1. / 255.0;  // Mat /= 255.0 multiplies by the reciprocal
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+                    cube[k][a][b] = D[(size_t)(img - 1 + k) * plane + (size_t)(i - 1 + a) * w + (j - 1 + b)] * inv;
+        grad[0] = 0.5 * (cube[1][1][2] - cube[1][1][0]);
+        grad[1] = 0.5 * (cube[1][2][1] - cube[1][0][1]);
+        grad[2] = 0.5 * (cube[2][1][1] - cube[0][1][1]);
+        hess[0][0] = cube[1][1][2] - 2 * cube[1][1][1] + cube[1][1][0];
+        hess[1][1] = cube[1][2][1] - 2 * cube[1][1][1] + cube[1][0][1];
+        hess[2][2] = cube[2][1][1] - 2 * cube[1][1][1] + cube[0][1][1];
+        hess[0][1] = hess[1][0] = 0.25 * (cube[1][2][2] - cube[1][2][0] - cube[1][0][2] + cube[1][0][0]);
+        hess[0][2] = hess[2][0] = 0.25 * (cube[2][1][2] - cube[2][1][0] - cube[0][1][2] + cube[0][1][0]);
+        hess[1][2] = hess[2][1] = 0.25 * (cube[2][2][1] - cube[2][0][1] - cube[0][2][1] + cube[0][0][1]);
+        if (!solve_normal3(hess, grad, res)) return 0;  // sift.cpp:333-335
+        res[0] *= -1;
+        res[1] *= -1;
+        res[2] *= -1;
+        if (fabs(res[0]) < 0.5 && fabs(res[1]) < 0.5 && fabs(res[2]) < 0.5) break;  // sift.cpp:339
+        j += (int)round(res[0]);
+        i += (int)round(res[1]);
+        img += (int)round(res[2]);
+        if (i < BORDER || i >= h - BORDER || j < BORDER || j >= w - BORDER || img < 1 || img > SCALES) return -1;
+    }
+    if (attempt == 5) return -1;  // sift.cpp:356
+    double dot = 0;
+    dot += grad[0] * res[0];
+    dot += grad[1] * res[1];
+    dot += grad[2] * res[2];
+    const double value = cube[1][1][1] + 0.5 * dot;                  // sift.cpp:360
+    if (!(fabs(value) * SCALES >= CONTRAST_THRESHOLD)) return -1;    // sift.cpp:363
+    const double hess_trace = hess[0][0] + hess[1][1];
+    const double hess_det = hess[0][0] * hess[1][1] - hess[0][1] * hess[1][0];
+    if (hess_det <= 0) return -1;                                     // sift.cpp:367
+    const double r1 = EIGEN_VALUE_RATIO + 1;
+    if (!((hess_trace * hess_trace) * EIGEN_VALUE_RATIO < (r1 * r1) * hess_det)) return -1;  // sift.cpp:374
+    const int keypt_octave = oct + (1 << 8) * img + (1 << 16) * (int)round((res[2] + 0.5) * 255);  // sift.cpp:375
+    const double keypt_pt_x = (j + res[0]) * (1 << oct);
+    const double keypt_pt_y = (i + res[1]) * (1 << oct);
+    const double keypt_size = SIGMA * exp2(img + res[2] / SCALES) * (1 << (oct + 1));  // sift.cpp:378
+    kpt.x = (float)keypt_pt_x;
+    kpt.y = (float)keypt_pt_y;
+    kpt.size = (float)keypt_size;
+    kpt.angle = -1.0f;
+    kpt.response = (float)fabs(value);
+    kpt.octave = keypt_octave;
+    kpt.class_id = -1;
+    kpt.pad = 0;
+    return img;
+}
+
+__device__ __forceinline__ double wave_sum_fixed(double v) {
+    // xor butterfly: every lane adds the same pairs in the same order
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// One wave per candidate: localize_extrema then get_keypoint_orientations
+// (sift.cpp:393-448).  Waves pull candidates from a per-frame cursor.
+__global__ __launch_bounds__(64) void k_localize_orient(Pyramid p, const Candidate *__restrict__ cand, int cand_cap,
+                                                         DevKeypoint *__restrict__ oriented, int kp_cap,
+                                                         FrameCounters *__restrict__ counters,
+                                                         int32_t *__restrict__ cursors) {
+    __shared__ double hist[BINS * 64];  // hist[bin][lane]: each lane owns a column
+    __shared__ double hsum[BINS];
+    __shared__ double smooth[BINS];
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x;
+    int n = counters[f].candidates;
+    if (n > cand_cap) n = cand_cap;
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(&cursors[f], 1);
+        idx = __shfl(idx, 0);
+        if (idx >= n) break;
+        const Candidate cd = cand[(size_t)f * cand_cap + idx];
+        DevKeypoint kpt;
+        const int layer = localize(p, f, cd.oct, cd.img, cd.i, cd.j, kpt);
+        // layer 0 (singular system) runs the orientation of a default keypoint
+        // in the reference, which emits nothing (sift.cpp:333-335, :401-409)
+        if (layer <= 0) continue;
+        const int oct = cd.oct;
+        const int w = p.w[oct], h = p.h[oct];
+        const double *L = p.gauss[oct] + gauss_off(p, oct, f, layer);
+        const int base_x = (int)round(kpt.x / double(1 << oct));  // sift.cpp:398
+        const int base_y = (int)round(kpt.y / double(1 << oct));
+        const double scale = SCALE_FACTOR * kpt.size / double(1 << (oct + 1));  // sift.cpp:401
+        const int radius = (int)round(scale * RADIUS_FACTOR);
+        const double weight_factor = -0.5 / (scale * scale);
+#pragma unroll
+        for (int b = 0; b < BINS; b++) hist[b * 64 + lane] = 0.0;
+        const int n1 = 2 * radius + 1;
+        const int total = n1 * n1;
+        const float inv_n1 = 1.0f / (float)n1;
+        for (int s = lane; s < total; s += 64) {
+            int qi = (int)((float)s * inv_n1);
+            int rj = s - qi * n1;
+            if (rj < 0) { qi--; rj += n1; }
+            if (rj >= n1) { qi++; rj -= n1; }
+            const int i = qi - radius, j = rj - radius;
+            const int y = base_y + i, x = base_x + j;
+            if (y > 0 && y < h - 1 && x > 0 && x < w - 1) {  // sift.cpp:407,409
+                const double *q = L + (size_t)y * w + x;
+                const double dx = q[1] - q[-1];
+                const double dy = q[-w] - q[w];
+                const double mag = sqrt(dx * dx + dy * dy);
+                const double orientation = (atan2(dy, dx) * 180) / PI;
+                const int index = ((int)round((orientation * BINS) / 360) % BINS + BINS) % BINS;  // sift.cpp:416
+                hist[index * 64 + lane] += exp(weight_factor * (i * i + j * j)) * mag;
+            }
+        }
+        __syncthreads();
+        for (int b = 0; b < BINS; b++) {
+            const double t = wave_sum_fixed(hist[b * 64 + lane]);
+            if (lane == b) hsum[b] = t;
+        }
+        __syncthreads();
+        if (lane < BINS) {
+            const int i = lane;
+            smooth[i] = (6 * hsum[i] + 4 * (hsum[(i + BINS - 1) % BINS] + hsum[(i + 1) % BINS]) +
+                         hsum[(i + BINS - 2) % BINS] + hsum[(i + 2) % BINS]) / 16.;  // sift.cpp:426-429
+        }
+        __syncthreads();
+        double max_orientation = smooth[0];
+        for (int b = 1; b < BINS; b++) max_orientation = fmax(max_orientation, smooth[b]);
+        bool is_peak = false;
+        double orientation = 0;
+        if (lane < BINS) {
+            const int i = lane;
+            const double l = smooth[(i + BINS - 1) % BINS], r = smooth[(i + 1) % BINS];
+            const double peak = smooth[i];
+            if (peak > l && peak > r && peak >= PEAK_RATIO * max_orientation) {  // sift.cpp:435-437
+                const double interpolated_index = fmod((i + 0.5 * (l - r) / (l + r - 2 * peak)), (double)BINS);
+                orientation = 360 - interpolated_index * 360 / BINS;
+                if (fabs(360 - orientation) < EPS) orientation = 0;
+                is_peak = true;
+            }
+        }
+        const int slot = wave_append(is_peak, &counters[f].oriented);
+        if (slot >= 0) {
+            if (slot < kp_cap) {
+                DevKeypoint nk = kpt;
+                nk.angle = (float)orientation;
+                oriented[(size_t)f * kp_cap + slot] = nk;
+            } else {
+                counters[f].overflow = 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
+                    FrameCounters *counters) {
+    const int w = p.w[oct], h = p.h[oct];
+    if (w <= 2 * BORDER || h <= 2 * BORDER) return;  // empty scan range (sift.cpp:188, :233)
+    dim3 grid((w - 2 * BORDER + 63) / 64, (h - 2 * BORDER + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_extrema, grid, dim3(256), 0, st, p, oct, cand, cand_cap, counters);
+}
+
+void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
+                            DevKeypoint *oriented, int kp_cap, FrameCounters *counters, int32_t *cursors) {
+    dim3 grid(512, nframes);
+    hipLaunchKernelGGL(k_localize_orient, grid, dim3(64), 0, st, p, cand, cand_cap, oriented, kp_cap, counters,
+                       cursors);
+}
+
+}  // namespace sa

@@ -1,0 +1,239 @@
+// Gaussian scale-space pyramid with fused difference-of-Gaussians.
+//
+// Replaces gen_gaussian_images (sift.cpp:132-156), gen_dog_images
+// (sift.cpp:161-177) and the base-image part of the constructor
+// (sift.cpp:40-42).  Every blur is one launch: a workgroup stages an input tile
+// plus halo in LDS, filters rows into a second LDS tile and filters columns
+// straight to HBM, writing the blurred level, the DoG level (blurred minus
+// input, sift.cpp:173) and, for level 3, the nearest-neighbour half-size base of
+// the next octave (sift.cpp:152-153) in the same pass.
+//
+// Arithmetic order is fixed (and contraction is off for this file) so that
+// results are bit-identical to a scalar CPU evaluation of the same filter:
+// rows accumulate taps left to right, s = c0*v0; s += ct*vt; columns start at
+// the centre tap and add symmetric pairs, s = cR*vR; s += c(R+t)*(v(R+t)+v(R-t)).
+#include "common.h"
+#include "kernels.h"
+
+namespace sa {
+
+namespace {
+
+constexpr int TW = 64;   // tile width  (outputs)
+constexpr int TH = 32;   // tile height (outputs)
+constexpr int CX = 8;    // consecutive outputs per thread in the row pass
+constexpr int CY = 8;    // consecutive outputs per thread in the column pass
+constexpr int NTHREADS = 256;
+
+template <int R>
+struct TileGeom {
+    static constexpr int ROWS = TH + 2 * R;
+    static constexpr int COLS = TW + 2 * R;
+    static constexpr int PIN = COLS | 1;  // odd pitches: lane<->row accesses hit distinct banks
+    static constexpr int PT = TW + 1;
+    static constexpr size_t LDS_BYTES = (size_t)ROWS * (PIN + PT) * sizeof(double);
+};
+
+// Row pass then column pass over the tile whose input (with halo) is in s_in.
+// store(gx, gy, blurred, centre_input) is called for every in-image output.
+template <int R, class Store>
+__device__ __forceinline__ void filter_tile(const Taps &taps, double *s_in, double *s_tmp, int tx0, int ty0, int w,
+                                            int h, Store store) {
+    using G = TileGeom<R>;
+    const int tid = threadIdx.x;
+    // rows: item -> (row, chunk of CX outputs); consecutive lanes take consecutive rows
+    for (int item = tid; item < G::ROWS * (TW / CX); item += NTHREADS) {
+        const int row = item % G::ROWS, cx = item / G::ROWS;
+        const double *p = s_in + row * G::PIN + cx * CX;
+        double v[CX + 2 * R];
+#pragma unroll
+        for (int k = 0; k < CX + 2 * R; k++) v[k] = p[k];
+        double *q = s_tmp + row * G::PT + cx * CX;
+#pragma unroll
+        for (int m = 0; m < CX; m++) {
+            double s = taps.c[0] * v[m];
+#pragma unroll
+            for (int t = 1; t <= 2 * R; t++) s += taps.c[t] * v[m + t];
+            q[m] = s;
+        }
+    }
+    __syncthreads();
+    // columns: one item per thread: column x, chunk of CY outputs
+    static_assert(TW * (TH / CY) == NTHREADS, "one column item per thread");
+    {
+        const int x = tid % TW, cy = tid / TW;
+        const double *p = s_tmp + (cy * CY) * G::PT + x;
+        double v[CY + 2 * R];
+#pragma unroll
+        for (int k = 0; k < CY + 2 * R; k++) v[k] = p[k * G::PT];
+        const int gx = tx0 + x;
+#pragma unroll
+        for (int m = 0; m < CY; m++) {
+            double s = taps.c[R] * v[m + R];
+#pragma unroll
+            for (int t = 1; t <= R; t++) s += taps.c[R + t] * (v[m + R + t] + v[m + R - t]);
+            const int gy = ty0 + cy * CY + m;
+            if (gx < w && gy < h) store(gx, gy, s, s_in[(cy * CY + m + R) * G::PIN + x + R]);
+        }
+    }
+}
+
+// One blur level of one octave for every frame of the batch (grid.z = frame).
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void k_blur_dog(const double *__restrict__ in, double *__restrict__ out,
+                                                        double *__restrict__ dog, double *__restrict__ next, int w,
+                                                        int h, int nw, int nh, size_t in_frame_stride,
+                                                        size_t dog_frame_stride, size_t next_frame_stride,
+                                                        Taps taps) {
+    using G = TileGeom<R>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *s_in = smem;
+    double *s_tmp = smem + G::ROWS * G::PIN;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t f = blockIdx.z;
+    in += f * in_frame_stride;
+    out += f * in_frame_stride;
+    dog += f * dog_frame_stride;
+    const bool interior = tx0 >= R && ty0 >= R && tx0 + TW + R <= w && ty0 + TH + R <= h;
+    for (int idx = threadIdx.x; idx < G::ROWS * G::COLS; idx += NTHREADS) {
+        const int y = idx / G::COLS, x = idx % G::COLS;
+        int gy = ty0 - R + y, gx = tx0 - R + x;
+        if (!interior) {
+            gy = reflect101(gy, h);
+            gx = reflect101(gx, w);
+        }
+        s_in[y * G::PIN + x] = in[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    double *nxt = next ? next + f * next_frame_stride : nullptr;
+    filter_tile<R>(taps, s_in, s_tmp, tx0, ty0, w, h, [=](int gx, int gy, double s, double c) {
+        const size_t o = (size_t)gy * w + gx;
+        out[o] = s;
+        dog[o] = s - c;
+        if (nxt && !((gx | gy) & 1)) {
+            const int hx = gx >> 1, hy = gy >> 1;
+            if (hx < nw && hy < nh) nxt[(size_t)hy * nw + hx] = s;
+        }
+    });
+}
+
+// gray u8 -> double -> 2x bilinear upsample -> base blur, one launch.
+// The upsample is resize(INTER_LINEAR) to twice the size: source coordinate
+// (d+0.5)/2-0.5 clamped at the edges; 8-bit inputs make it exact in double.
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void k_base(const uint8_t *__restrict__ frames, int W, int H,
+                                                    double *__restrict__ out, size_t out_frame_stride, Taps taps) {
+    using G = TileGeom<R>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *s_in = smem;
+    double *s_tmp = smem + G::ROWS * G::PIN;
+    const int w = 2 * W, h = 2 * H;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t f = blockIdx.z;
+    const uint8_t *src = frames + f * (size_t)W * H;
+    out += f * out_frame_stride;
+    for (int idx = threadIdx.x; idx < G::ROWS * G::COLS; idx += NTHREADS) {
+        const int y = idx / G::COLS, x = idx % G::COLS;
+        const int gy = reflect101(ty0 - R + y, h), gx = reflect101(tx0 - R + x, w);
+        // even d = 2k: 0.25*s[k-1] + 0.75*s[k]; odd d = 2k+1: 0.75*s[k] + 0.25*s[k+1]; clamped
+        int sx = (gx - 1) >> 1, sy = (gy - 1) >> 1;  // floor((d-1)/2)
+        double fx = (gx & 1) ? 0.25 : 0.75, fy = (gy & 1) ? 0.25 : 0.75;
+        if (sx < 0) { sx = 0; fx = 0; }
+        if (sx >= W - 1) { sx = W - 1; fx = 0; }
+        if (sy < 0) { sy = 0; fy = 0; }
+        if (sy >= H - 1) { sy = H - 1; fy = 0; }
+        const int sx1 = min(sx + 1, W - 1), sy1 = min(sy + 1, H - 1);
+        const double a = src[(size_t)sy * W + sx], b = src[(size_t)sy * W + sx1];
+        const double c = src[(size_t)sy1 * W + sx], d = src[(size_t)sy1 * W + sx1];
+        const double r0 = a * (1.0 - fx) + b * fx, r1 = c * (1.0 - fx) + d * fx;
+        s_in[y * G::PIN + x] = r0 * (1.0 - fy) + r1 * fy;
+    }
+    __syncthreads();
+    filter_tile<R>(taps, s_in, s_tmp, tx0, ty0, w, h,
+                   [=](int gx, int gy, double s, double) { out[(size_t)gy * w + gx] = s; });
+}
+
+template <int R>
+void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps) {
+    const int w = p.w[oct], h = p.h[oct];
+    const size_t plane = (size_t)w * h;
+    const double *in = p.gauss[oct] + (size_t)(lvl - 1) * plane;
+    double *out = p.gauss[oct] + (size_t)lvl * plane;
+    double *dog = p.dog[oct] + (size_t)(lvl - 1) * plane;
+    double *next = nullptr;
+    int nw = 0, nh = 0;
+    size_t next_stride = 0;
+    if (lvl == IMAGES - 3 && oct + 1 < p.octaves) {
+        next = p.gauss[oct + 1];
+        nw = p.w[oct + 1];
+        nh = p.h[oct + 1];
+        next_stride = (size_t)IMAGES * nw * nh;
+    }
+    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, nframes);
+    hipLaunchKernelGGL(k_blur_dog<R>, grid, dim3(NTHREADS), TileGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h, nw,
+                       nh, (size_t)IMAGES * plane, (size_t)NDOG * plane, next_stride, taps);
+}
+
+// cvtColor(BGR2GRAY) on 8-bit data (sift.cpp:29): OpenCV 4.x integer formula
+// with 15-bit coefficients B 3735, G 19235, R 9798 and a rounding shift.
+__global__ void k_bgr_to_gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+template <int R>
+int set_lds_attr() {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blur_dog<R>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileGeom<R>::LDS_BYTES);
+    return e1 == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+int pyramid_init_attributes() {
+    int rc = 0;
+    rc |= set_lds_attr<5>();
+    rc |= set_lds_attr<6>();
+    rc |= set_lds_attr<8>();
+    rc |= set_lds_attr<10>();
+    rc |= set_lds_attr<13>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_base<5>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileGeom<5>::LDS_BYTES);
+    if (e != hipSuccess) rc = -1;
+    return rc;
+}
+
+void launch_bgr_to_gray(hipStream_t st, const uint8_t *bgr, uint8_t *gray, size_t npix) {
+    const int block = 256;
+    size_t want = (npix + block - 1) / block;
+    const int grid = (int)(want < 2048 ? (want ? want : 1) : 2048);
+    hipLaunchKernelGGL(k_bgr_to_gray, dim3(grid), dim3(block), 0, st, bgr, gray, npix);
+}
+
+int blur_radius_supported(int r) { return r == 5 || r == 6 || r == 8 || r == 10 || r == 13; }
+
+void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframes, const Pyramid &p, const Taps &taps,
+                 int ntaps) {
+    (void)ntaps;  // sigma 1.2489996 -> 11 taps
+    const int w = 2 * W, h = 2 * H;
+    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, nframes);
+    hipLaunchKernelGGL(k_base<5>, grid, dim3(NTHREADS), TileGeom<5>::LDS_BYTES, st, frames, W, H, p.gauss[0],
+                       (size_t)IMAGES * w * h, taps);
+}
+
+void launch_blur_dog(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps) {
+    switch (ntaps / 2) {
+        case 5: launch_blur_r<5>(st, p, oct, lvl, nframes, taps); break;
+        case 6: launch_blur_r<6>(st, p, oct, lvl, nframes, taps); break;
+        case 8: launch_blur_r<8>(st, p, oct, lvl, nframes, taps); break;
+        case 10: launch_blur_r<10>(st, p, oct, lvl, nframes, taps); break;
+        case 13: launch_blur_r<13>(st, p, oct, lvl, nframes, taps); break;
+        default: break;  // rejected on the host before any launch
+    }
+}
+
+}  // namespace sa

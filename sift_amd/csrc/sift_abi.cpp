@@ -1,0 +1,676 @@
+// C ABI of the MI355X SIFT engine: contexts, frame batches, the exec()
+// pipeline as a sequence of HIP launches on one stream, result download, and
+// the matcher entry points.  See include/sift_amd.h for the contract.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace sa;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(SIFT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+// cvRound: round half to even
+int cv_round(double v) { return (int)std::lrint(v); }
+
+// getGaussianKernel(n, sigma, CV_64F) as OpenCV 4.x builds it: taps on doubled
+// integer coordinates, t = exp(x*x * (-0.125/sigma^2)), sum = 2*sum(t) + 1,
+// every tap multiplied by 1/sum, centre tap = 1/sum.  n = cvRound(8*sigma+1)|1
+// (GaussianBlur on a non-8-bit depth; sift.cpp:42, :150).
+int gaussian_taps(double sigma, Taps &taps) {
+    const int n = cv_round(sigma * 4 * 2 + 1) | 1;
+    if (n > MAX_TAPS) return -1;
+    const int n2 = (n - 1) / 2;
+    const double scale2x = -0.125 / (sigma * sigma);
+    double t[MAX_TAPS];
+    double sum = 0.0;
+    int x = 1 - n;
+    for (int i = 0; i < n2; i++, x += 2) {
+        t[i] = std::exp((double)(x * x) * scale2x);
+        sum += t[i];
+    }
+    sum *= 2.0;
+    sum += 1.0;
+    const double mul1 = 1.0 / sum;
+    for (int i = 0; i < MAX_TAPS; i++) taps.c[i] = 0.0;
+    for (int i = 0; i < n2; i++) {
+        const double v = t[i] * mul1;
+        taps.c[i] = v;
+        taps.c[n - 1 - i] = v;
+    }
+    taps.c[n2] = 1.0 * mul1;
+    return n;
+}
+
+}  // namespace
+
+struct sift_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void *knn_scratch = nullptr;
+    size_t knn_scratch_bytes = 0;
+    void *knn_io = nullptr;  // device staging of the host-buffer matcher calls
+    size_t knn_io_bytes = 0;
+    sift_batch *cached = nullptr;  // workspace of the single-image calls
+};
+
+struct sift_batch {
+    sift_ctx *ctx = nullptr;
+    int w = 0, h = 0, max_frames = 0;
+    Pyramid pyr{};
+    uint8_t *d_frames = nullptr;
+    uint8_t *d_bgr = nullptr;  // one frame of BGR staging, allocated on first use
+    Candidate *d_cand = nullptr;
+    int cand_cap = 0;
+    DevKeypoint *d_oriented = nullptr, *d_sorted = nullptr, *d_final = nullptr;
+    uint8_t *d_flags = nullptr;
+    int kp_cap = 0;
+    uint8_t *d_desc = nullptr;
+    FrameCounters *d_counters = nullptr;
+    int32_t *d_cursors = nullptr;  // [2][max_frames]: localize cursor, descriptor cursor
+    Taps base_taps{};
+    int base_ntaps = 0;
+    Taps lvl_taps[IMAGES]{};
+    int lvl_ntaps[IMAGES]{};
+    std::vector<hipEvent_t> events;
+};
+
+extern "C" {
+
+const char *sift_last_error(void) { return g_last_error.c_str(); }
+
+int sift_device_count(int *count) {
+    if (!count) return fail(SIFT_ERR_INVALID, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return SIFT_OK;
+}
+
+int sift_ctx_create(int device, sift_ctx **out) {
+    if (!out) return fail(SIFT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(SIFT_ERR_INVALID, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    sift_ctx *c = new sift_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(SIFT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    if (pyramid_init_attributes() != 0) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return fail(SIFT_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    }
+    *out = c;
+    return SIFT_OK;
+}
+
+int sift_ctx_destroy(sift_ctx *ctx) {
+    if (!ctx) return SIFT_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->cached) sift_batch_destroy(ctx->cached);
+    if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
+    if (ctx->knn_io) hipFree(ctx->knn_io);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SIFT_OK;
+}
+
+int sift_ctx_stream(sift_ctx *ctx, void **stream) {
+    if (!ctx || !stream) return fail(SIFT_ERR_INVALID, "NULL argument");
+    *stream = (void *)ctx->stream;
+    return SIFT_OK;
+}
+
+int sift_ctx_synchronize(sift_ctx *ctx) {
+    if (!ctx) return fail(SIFT_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SIFT_OK;
+}
+
+int sift_num_octaves(int w, int h) {
+    if (w <= 0 || h <= 0) return 0;
+    return (int)std::round(std::log2((double)std::min(w, h)));  // sift.cpp:36
+}
+
+int sift_octave_dims(int w, int h, int oct, int *ow, int *oh) {
+    if (w <= 0 || h <= 0 || oct < 0 || !ow || !oh) return fail(SIFT_ERR_INVALID, "bad argument");
+    int cw = 2 * w, ch = 2 * h;  // sift.cpp:40
+    for (int o = 0; o < oct; o++) {
+        cw = cv_round(cw * 0.5);  // resize(fx=fy=0.5): dsize = cvRound(dim*0.5), sift.cpp:153
+        ch = cv_round(ch * 0.5);
+    }
+    *ow = cw;
+    *oh = ch;
+    return SIFT_OK;
+}
+
+int sift_batch_destroy(sift_batch *b) {
+    if (!b) return SIFT_OK;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    for (int o = 0; o < MAX_OCTAVES; o++) {
+        if (b->pyr.gauss[o]) hipFree(b->pyr.gauss[o]);
+        if (b->pyr.dog[o]) hipFree(b->pyr.dog[o]);
+    }
+    hipFree(b->d_frames);
+    hipFree(b->d_bgr);
+    hipFree(b->d_cand);
+    hipFree(b->d_oriented);
+    hipFree(b->d_sorted);
+    hipFree(b->d_final);
+    hipFree(b->d_flags);
+    hipFree(b->d_desc);
+    hipFree(b->d_counters);
+    hipFree(b->d_cursors);
+    for (hipEvent_t e : b->events) hipEventDestroy(e);
+    if (b->ctx->cached == b) b->ctx->cached = nullptr;
+    delete b;
+    return SIFT_OK;
+}
+
+int sift_batch_create(sift_ctx *ctx, int w, int h, int max_frames, int max_keypoints_per_frame, sift_batch **out) {
+    if (!ctx || !out) return fail(SIFT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (w < 2 || h < 2 || max_frames < 1) return fail(SIFT_ERR_INVALID, "frame size or count out of range");
+    if ((int64_t)w * h > (int64_t)1 << 28) return fail(SIFT_ERR_INVALID, "frame too large");
+    const int octaves = sift_num_octaves(w, h);
+    if (octaves < 1 || octaves > MAX_OCTAVES) return fail(SIFT_ERR_INVALID, "octave count out of range");
+    HIP_TRY(hipSetDevice(ctx->device));
+    sift_batch *b = new sift_batch();
+    b->ctx = ctx;
+    b->w = w;
+    b->h = h;
+    b->max_frames = max_frames;
+    b->pyr.octaves = octaves;
+    // kernel taps: base blur (sift.cpp:41) and the incremental sigmas (sift.cpp:134-141)
+    {
+        const double diff = std::max(std::sqrt(SIGMA * SIGMA - 4 * (ASSUMED_BLUR * ASSUMED_BLUR)), 0.1);
+        b->base_ntaps = gaussian_taps(diff, b->base_taps);
+        const double k = std::pow(2, 1.0 / SCALES);
+        double prev = SIGMA;
+        for (int i = 1; i < IMAGES; i++) {
+            const double now = prev * k;
+            const double sig = std::sqrt(now * now - prev * prev);
+            b->lvl_ntaps[i] = gaussian_taps(sig, b->lvl_taps[i]);
+            prev = now;
+        }
+        bool ok = b->base_ntaps == 11;
+        for (int i = 1; i < IMAGES; i++) ok = ok && b->lvl_ntaps[i] > 0 && blur_radius_supported(b->lvl_ntaps[i] / 2);
+        if (!ok) {
+            delete b;
+            return fail(SIFT_ERR_INVALID, "unexpected Gaussian tap count");
+        }
+    }
+    const int64_t px = (int64_t)w * h;
+    int cap = max_keypoints_per_frame > 0 ? max_keypoints_per_frame : (int)std::max<int64_t>(8192, px / 16);
+    b->cand_cap = cap;
+    b->kp_cap = cap;
+    auto cleanup = [&](hipError_t e, const char *what) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        sift_batch_destroy(b);
+        return fail(SIFT_ERR_HIP, msg);
+    };
+    hipError_t e;
+    for (int o = 0; o < octaves; o++) {
+        int ow, oh;
+        sift_octave_dims(w, h, o, &ow, &oh);
+        if (ow < 1 || oh < 1) {
+            sift_batch_destroy(b);
+            return fail(SIFT_ERR_INVALID, "pyramid octave collapsed to zero size");
+        }
+        b->pyr.w[o] = ow;
+        b->pyr.h[o] = oh;
+        const size_t plane = (size_t)ow * oh * sizeof(double);
+        if ((e = hipMalloc((void **)&b->pyr.gauss[o], plane * IMAGES * max_frames)) != hipSuccess)
+            return cleanup(e, "hipMalloc(gauss)");
+        if ((e = hipMalloc((void **)&b->pyr.dog[o], plane * NDOG * max_frames)) != hipSuccess)
+            return cleanup(e, "hipMalloc(dog)");
+    }
+    const size_t F = (size_t)max_frames;
+    if ((e = hipMalloc((void **)&b->d_frames, F * px)) != hipSuccess) return cleanup(e, "hipMalloc(frames)");
+    if ((e = hipMalloc((void **)&b->d_cand, F * cap * sizeof(Candidate))) != hipSuccess) return cleanup(e, "hipMalloc(cand)");
+    if ((e = hipMalloc((void **)&b->d_oriented, F * cap * sizeof(DevKeypoint))) != hipSuccess) return cleanup(e, "hipMalloc(kp)");
+    if ((e = hipMalloc((void **)&b->d_sorted, F * cap * sizeof(DevKeypoint))) != hipSuccess) return cleanup(e, "hipMalloc(kp)");
+    if ((e = hipMalloc((void **)&b->d_final, F * cap * sizeof(DevKeypoint))) != hipSuccess) return cleanup(e, "hipMalloc(kp)");
+    if ((e = hipMalloc((void **)&b->d_flags, F * cap * 2)) != hipSuccess) return cleanup(e, "hipMalloc(flags)");
+    if ((e = hipMalloc((void **)&b->d_desc, F * cap * 128)) != hipSuccess) return cleanup(e, "hipMalloc(desc)");
+    if ((e = hipMalloc((void **)&b->d_counters, F * sizeof(FrameCounters))) != hipSuccess) return cleanup(e, "hipMalloc(counters)");
+    if ((e = hipMalloc((void **)&b->d_cursors, 2 * F * sizeof(int32_t))) != hipSuccess) return cleanup(e, "hipMalloc(cursors)");
+    if ((e = hipMemset(b->d_counters, 0, F * sizeof(FrameCounters))) != hipSuccess) return cleanup(e, "hipMemset");
+    *out = b;
+    return SIFT_OK;
+}
+
+int sift_batch_frames_device_ptr(sift_batch *b, void **dptr) {
+    if (!b || !dptr) return fail(SIFT_ERR_INVALID, "NULL argument");
+    *dptr = b->d_frames;
+    return SIFT_OK;
+}
+
+int sift_batch_upload_gray8(sift_batch *b, int frame, const uint8_t *gray, size_t stride) {
+    if (!b || !gray) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (frame < 0 || frame >= b->max_frames) return fail(SIFT_ERR_INVALID, "frame index out of range");
+    if (stride < (size_t)b->w) return fail(SIFT_ERR_INVALID, "stride smaller than width");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    uint8_t *dst = b->d_frames + (size_t)frame * b->w * b->h;
+    HIP_TRY(hipMemcpy2DAsync(dst, b->w, gray, stride, b->w, b->h, hipMemcpyHostToDevice, b->ctx->stream));
+    return SIFT_OK;
+}
+
+int sift_batch_upload_bgr8(sift_batch *b, int frame, const uint8_t *bgr, size_t stride) {
+    if (!b || !bgr) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (frame < 0 || frame >= b->max_frames) return fail(SIFT_ERR_INVALID, "frame index out of range");
+    if (stride < (size_t)b->w * 3) return fail(SIFT_ERR_INVALID, "stride smaller than 3*width");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    const size_t px = (size_t)b->w * b->h;
+    if (!b->d_bgr) HIP_TRY(hipMalloc((void **)&b->d_bgr, px * 3));
+    HIP_TRY(hipMemcpy2DAsync(b->d_bgr, (size_t)b->w * 3, bgr, stride, (size_t)b->w * 3, b->h, hipMemcpyHostToDevice,
+                             b->ctx->stream));
+    launch_bgr_to_gray(b->ctx->stream, b->d_bgr, b->d_frames + (size_t)frame * px, px);
+    HIP_TRY(hipGetLastError());
+    // the staging buffer is reused by the next upload
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return SIFT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct StageTimer {
+    sift_batch *b;
+    bool on;
+    size_t used = 0;
+    std::vector<int> stage_of;
+    hipStream_t st;
+    int begin(int stage) {
+        if (!on) return 0;
+        while (b->events.size() < used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            b->events.push_back(e);
+        }
+        stage_of.push_back(stage);
+        return hipEventRecord(b->events[used], st) == hipSuccess ? 0 : -1;
+    }
+    int end() {
+        if (!on) return 0;
+        int rc = hipEventRecord(b->events[used + 1], st) == hipSuccess ? 0 : -1;
+        used += 2;
+        return rc;
+    }
+};
+
+int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
+    sift_ctx *ctx = b->ctx;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipSetDevice(ctx->device));
+    StageTimer tm{b, times != nullptr, 0, {}, st};
+    HIP_TRY(hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(FrameCounters), st));
+    HIP_TRY(hipMemsetAsync(b->d_cursors, 0, 2 * (size_t)b->max_frames * sizeof(int32_t), st));
+#define TIMED(stage, call)                                              \
+    do {                                                                \
+        if (tm.begin(stage)) return fail(SIFT_ERR_HIP, "hipEventRecord"); \
+        call;                                                           \
+        if (tm.end()) return fail(SIFT_ERR_HIP, "hipEventRecord");      \
+    } while (0)
+    TIMED(SIFT_STAGE_BASE, launch_base(st, b->d_frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
+    for (int o = 0; o < b->pyr.octaves; o++)
+        for (int lvl = 1; lvl < IMAGES; lvl++)
+            TIMED(SIFT_STAGE_BLUR_DOG, launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
+    for (int o = 0; o < b->pyr.octaves; o++)
+        TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
+    TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_oriented, b->kp_cap,
+                                                      b->d_counters, b->d_cursors));
+    TIMED(SIFT_STAGE_CLEAN,
+          launch_clean(st, n, b->d_oriented, b->d_sorted, b->d_final, b->d_flags, b->kp_cap, b->d_counters));
+    TIMED(SIFT_STAGE_DESCRIPTOR, launch_descriptors(st, b->pyr, n, b->d_final, b->kp_cap, b->d_counters,
+                                                    b->d_cursors + b->max_frames, b->d_desc));
+#undef TIMED
+    HIP_TRY(hipGetLastError());
+    if (times) {
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memset(times, 0, sizeof(*times));
+        for (size_t i = 0; i < tm.stage_of.size(); i++) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, b->events[2 * i], b->events[2 * i + 1]));
+            times->ms[tm.stage_of[i]] += ms;
+            times->launches[tm.stage_of[i]] += 1;
+        }
+    }
+    return SIFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sift_batch_run(sift_batch *b, int n_frames) {
+    if (!b) return fail(SIFT_ERR_INVALID, "batch is NULL");
+    if (n_frames < 1 || n_frames > b->max_frames) return fail(SIFT_ERR_INVALID, "n_frames out of range");
+    return run_pipeline(b, n_frames, nullptr);
+}
+
+int sift_batch_run_profiled(sift_batch *b, int n_frames, sift_stage_times *times) {
+    if (!b || !times) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (n_frames < 1 || n_frames > b->max_frames) return fail(SIFT_ERR_INVALID, "n_frames out of range");
+    return run_pipeline(b, n_frames, times);
+}
+
+int sift_batch_counts(sift_batch *b, int n_frames, sift_frame_counts *counts) {
+    if (!b || !counts) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (n_frames < 1 || n_frames > b->max_frames) return fail(SIFT_ERR_INVALID, "n_frames out of range");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    static_assert(sizeof(sift_frame_counts) == sizeof(FrameCounters), "layout");
+    HIP_TRY(hipMemcpyAsync(counts, b->d_counters, (size_t)n_frames * sizeof(FrameCounters), hipMemcpyDeviceToHost,
+                           b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    bool overflow = false;
+    for (int f = 0; f < n_frames; f++) {
+        if (counts[f].candidates > b->cand_cap || counts[f].oriented > b->kp_cap) counts[f].overflow = 1;
+        overflow = overflow || counts[f].overflow;
+    }
+    if (overflow) return fail(SIFT_ERR_OVERFLOW, "a frame produced more candidates or keypoints than the batch capacity");
+    return SIFT_OK;
+}
+
+int sift_batch_download(sift_batch *b, int frame, int capacity, sift_keypoint *keypoints, uint8_t *desc_u8,
+                        double *desc_f64, int32_t *n_out) {
+    if (!b) return fail(SIFT_ERR_INVALID, "batch is NULL");
+    if (frame < 0 || frame >= b->max_frames) return fail(SIFT_ERR_INVALID, "frame index out of range");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    FrameCounters fc;
+    HIP_TRY(hipMemcpyAsync(&fc, b->d_counters + frame, sizeof(fc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int n = fc.keypoints;
+    if (n_out) *n_out = n;
+    if (n > capacity) return fail(SIFT_ERR_INVALID, "capacity smaller than the frame's keypoint count");
+    if (n == 0) return SIFT_OK;
+    if (keypoints) {
+        std::vector<DevKeypoint> tmp((size_t)n);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), b->d_final + (size_t)frame * b->kp_cap, (size_t)n * sizeof(DevKeypoint),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < n; i++) std::memcpy(&keypoints[i], &tmp[i], sizeof(sift_keypoint));
+    }
+    if (desc_u8 || desc_f64) {
+        std::vector<uint8_t> tmp;
+        uint8_t *dst = desc_u8;
+        if (!dst) {
+            tmp.resize((size_t)n * 128);
+            dst = tmp.data();
+        }
+        HIP_TRY(hipMemcpyAsync(dst, b->d_desc + (size_t)frame * b->kp_cap * 128, (size_t)n * 128,
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (desc_f64)
+            for (size_t i = 0; i < (size_t)n * 128; i++) desc_f64[i] = (double)dst[i];
+    }
+    return SIFT_OK;
+}
+
+int sift_batch_result_device_ptrs(sift_batch *b, int frame, void **keypoints, void **desc_u8) {
+    if (!b) return fail(SIFT_ERR_INVALID, "batch is NULL");
+    if (frame < 0 || frame >= b->max_frames) return fail(SIFT_ERR_INVALID, "frame index out of range");
+    if (keypoints) *keypoints = b->d_final + (size_t)frame * b->kp_cap;
+    if (desc_u8) *desc_u8 = b->d_desc + (size_t)frame * b->kp_cap * 128;
+    return SIFT_OK;
+}
+
+int sift_batch_get_level(sift_batch *b, int frame, int oct, int lvl, int kind, double *out) {
+    if (!b || !out) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (frame < 0 || frame >= b->max_frames || oct < 0 || oct >= b->pyr.octaves)
+        return fail(SIFT_ERR_INVALID, "frame or octave out of range");
+    const int nl = kind == SIFT_LEVEL_GAUSS ? IMAGES : NDOG;
+    if ((kind != SIFT_LEVEL_GAUSS && kind != SIFT_LEVEL_DOG) || lvl < 0 || lvl >= nl)
+        return fail(SIFT_ERR_INVALID, "level out of range");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    const size_t plane = (size_t)b->pyr.w[oct] * b->pyr.h[oct];
+    const double *src = kind == SIFT_LEVEL_GAUSS ? b->pyr.gauss[oct] + gauss_off(b->pyr, oct, frame, lvl)
+                                                 : b->pyr.dog[oct] + dog_off(b->pyr, oct, frame, lvl);
+    HIP_TRY(hipMemcpyAsync(out, src, plane * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return SIFT_OK;
+}
+
+int sift_batch_get_candidates(sift_batch *b, int frame, int capacity, int32_t *quads, int32_t *n_out) {
+    if (!b || !n_out) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (frame < 0 || frame >= b->max_frames) return fail(SIFT_ERR_INVALID, "frame index out of range");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    FrameCounters fc;
+    HIP_TRY(hipMemcpyAsync(&fc, b->d_counters + frame, sizeof(fc), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    const int n = std::min(fc.candidates, b->cand_cap);
+    *n_out = n;
+    if (!quads || n == 0) return SIFT_OK;
+    if (n > capacity) return fail(SIFT_ERR_INVALID, "capacity too small");
+    static_assert(sizeof(Candidate) == 16, "layout");
+    HIP_TRY(hipMemcpyAsync(quads, b->d_cand + (size_t)frame * b->cand_cap, (size_t)n * sizeof(Candidate),
+                           hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return SIFT_OK;
+}
+
+int sift_batch_get_oriented(sift_batch *b, int frame, int capacity, sift_keypoint *kps, int32_t *n_out) {
+    if (!b || !n_out) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (frame < 0 || frame >= b->max_frames) return fail(SIFT_ERR_INVALID, "frame index out of range");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    FrameCounters fc;
+    HIP_TRY(hipMemcpyAsync(&fc, b->d_counters + frame, sizeof(fc), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    const int n = std::min(fc.oriented, b->kp_cap);
+    *n_out = n;
+    if (!kps || n == 0) return SIFT_OK;
+    if (n > capacity) return fail(SIFT_ERR_INVALID, "capacity too small");
+    std::vector<DevKeypoint> tmp((size_t)n);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), b->d_oriented + (size_t)frame * b->kp_cap, (size_t)n * sizeof(DevKeypoint),
+                           hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    for (int i = 0; i < n; i++) std::memcpy(&kps[i], &tmp[i], sizeof(sift_keypoint));
+    return SIFT_OK;
+}
+
+// ---- single image ---------------------------------------------------------
+
+static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, bool bgr, sift_result *out) {
+    if (!ctx || !img || !out) return fail(SIFT_ERR_INVALID, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    sift_batch *b = ctx->cached;
+    if (!b || b->w != w || b->h != h) {
+        if (b) sift_batch_destroy(b);
+        ctx->cached = nullptr;
+        int rc = sift_batch_create(ctx, w, h, 1, 0, &b);
+        if (rc) return rc;
+        ctx->cached = b;
+    }
+    int rc = bgr ? sift_batch_upload_bgr8(b, 0, img, stride) : sift_batch_upload_gray8(b, 0, img, stride);
+    if (rc) return rc;
+    if ((rc = sift_batch_run(b, 1))) return rc;
+    sift_frame_counts fc;
+    if ((rc = sift_batch_counts(b, 1, &fc))) return rc;
+    out->counts = fc;
+    out->octaves = b->pyr.octaves;
+    out->n = fc.keypoints;
+    if (fc.keypoints > 0) {
+        out->keypoints = (sift_keypoint *)std::malloc(sizeof(sift_keypoint) * (size_t)fc.keypoints);
+        out->descriptors = (double *)std::malloc(sizeof(double) * 128 * (size_t)fc.keypoints);
+        if (!out->keypoints || !out->descriptors) {
+            sift_result_free(out);
+            return fail(SIFT_ERR_INVALID, "out of host memory");
+        }
+        int32_t n = 0;
+        rc = sift_batch_download(b, 0, fc.keypoints, out->keypoints, nullptr, out->descriptors, &n);
+        if (rc) {
+            sift_result_free(out);
+            return rc;
+        }
+    }
+    return SIFT_OK;
+}
+
+int sift_extract_gray8(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, sift_result *out) {
+    return extract_common(ctx, gray, w, h, stride, false, out);
+}
+
+int sift_extract_bgr8(sift_ctx *ctx, const uint8_t *bgr, int w, int h, size_t stride, sift_result *out) {
+    return extract_common(ctx, bgr, w, h, stride, true, out);
+}
+
+int sift_result_free(sift_result *r) {
+    if (!r) return SIFT_OK;
+    std::free(r->keypoints);
+    std::free(r->descriptors);
+    r->keypoints = nullptr;
+    r->descriptors = nullptr;
+    r->n = 0;
+    return SIFT_OK;
+}
+
+int sift_result_get_f32(const sift_result *r, float *out) {
+    if (!r || (!out && r->n > 0)) return fail(SIFT_ERR_INVALID, "NULL argument");
+    for (size_t i = 0; i < (size_t)r->n * 128; i++) out[i] = (float)r->descriptors[i];  // sift.cpp:108
+    return SIFT_OK;
+}
+
+// ---- matcher ----------------------------------------------------------------
+
+static int ensure_bytes(void **buf, size_t *have, size_t want) {
+    if (*have >= want) return SIFT_OK;
+    if (*buf) {
+        hipError_t e = hipFree(*buf);
+        *buf = nullptr;
+        *have = 0;
+        if (e != hipSuccess) return fail(SIFT_ERR_HIP, std::string("hipFree: ") + hipGetErrorString(e));
+    }
+    HIP_TRY(hipMalloc(buf, want));
+    *have = want;
+    return SIFT_OK;
+}
+
+int sift_knn2_device(sift_ctx *ctx, const void *d_q, int nq, const void *d_t, int nt, int train_index_base,
+                     void *d_out) {
+    if (!ctx || (nq > 0 && (!d_q || !d_out)) || (nt > 0 && !d_t)) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (nq < 0 || nt < 0) return fail(SIFT_ERR_INVALID, "negative count");
+    if (nq == 0) return SIFT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t need = knn_scratch_bytes(nq, nt);
+    if (need > ctx->knn_scratch_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc = ensure_bytes(&ctx->knn_scratch, &ctx->knn_scratch_bytes, need);
+        if (rc) return rc;
+    }
+    launch_knn2(ctx->stream, (const uint8_t *)d_q, nq, (const uint8_t *)d_t, nt, train_index_base, (sift_knn2 *)d_out,
+                ctx->knn_scratch);
+    HIP_TRY(hipGetLastError());
+    return SIFT_OK;
+}
+
+int sift_knn2_merge_device(sift_ctx *ctx, const void *d_parts, int nparts, int nq, void *d_out, void *d_accept) {
+    if (!ctx || !d_parts) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (nparts < 1 || nq < 0) return fail(SIFT_ERR_INVALID, "bad count");
+    HIP_TRY(hipSetDevice(ctx->device));
+    launch_knn2_merge(ctx->stream, (const sift_knn2 *)d_parts, nparts, nq, (sift_knn2 *)d_out, (uint8_t *)d_accept);
+    HIP_TRY(hipGetLastError());
+    return SIFT_OK;
+}
+
+int sift_knn2_u8(sift_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, sift_knn2 *out, uint8_t *accept) {
+    if (!ctx || (nq > 0 && (!q || !out)) || (nt > 0 && !t)) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (nq < 0 || nt < 0) return fail(SIFT_ERR_INVALID, "negative count");
+    if (nq == 0) return SIFT_OK;
+    for (size_t i = 0; i < (size_t)nq * 128; i++)
+        if (q[i] > 127) return fail(SIFT_ERR_NOT_INTEGRAL, "query descriptor value above 127");
+    for (size_t i = 0; i < (size_t)nt * 128; i++)
+        if (t[i] > 127) return fail(SIFT_ERR_NOT_INTEGRAL, "train descriptor value above 127");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t qb = ((size_t)nq * 128 + 255) & ~(size_t)255, tb = ((size_t)nt * 128 + 255) & ~(size_t)255;
+    const size_t ob = ((size_t)nq * sizeof(sift_knn2) + 255) & ~(size_t)255;
+    const size_t ab = ((size_t)nq + 255) & ~(size_t)255;
+    const size_t need = qb + tb + 2 * ob + ab;
+    if (need > ctx->knn_io_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc = ensure_bytes(&ctx->knn_io, &ctx->knn_io_bytes, need);
+        if (rc) return rc;
+    }
+    char *base = (char *)ctx->knn_io;
+    uint8_t *dq = (uint8_t *)base, *dt = (uint8_t *)(base + qb);
+    sift_knn2 *dpart = (sift_knn2 *)(base + qb + tb), *dout = (sift_knn2 *)(base + qb + tb + ob);
+    uint8_t *dacc = (uint8_t *)(base + qb + tb + 2 * ob);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dq, q, (size_t)nq * 128, hipMemcpyHostToDevice, st));
+    if (nt > 0) HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nt * 128, hipMemcpyHostToDevice, st));
+    int rc = sift_knn2_device(ctx, dq, nq, dt, nt, 0, dpart);
+    if (rc) return rc;
+    rc = sift_knn2_merge_device(ctx, dpart, 1, nq, dout, dacc);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)nq * sizeof(sift_knn2), hipMemcpyDeviceToHost, st));
+    if (accept) HIP_TRY(hipMemcpyAsync(accept, dacc, (size_t)nq, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SIFT_OK;
+}
+
+int sift_knn2_f32(sift_ctx *ctx, const float *q, int nq, const float *t, int nt, sift_knn2 *out, uint8_t *accept) {
+    if (!ctx || (nq > 0 && (!q || !out)) || (nt > 0 && !t)) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (nq < 0 || nt < 0) return fail(SIFT_ERR_INVALID, "negative count");
+    std::vector<uint8_t> qb((size_t)nq * 128), tb((size_t)nt * 128);
+    auto quantise = [](const float *src, std::vector<uint8_t> &dst) {
+        for (size_t i = 0; i < dst.size(); i++) {
+            const float v = src[i];
+            if (!(v >= 0.0f && v <= 127.0f) || v != std::floor(v)) return false;
+            dst[i] = (uint8_t)v;
+        }
+        return true;
+    };
+    if (!quantise(q, qb) || !quantise(t, tb))
+        return fail(SIFT_ERR_NOT_INTEGRAL, "descriptor values must be integers in [0,127]");
+    return sift_knn2_u8(ctx, qb.data(), nq, tb.data(), nt, out, accept);
+}
+
+int sift_match_min_dist_filter(const sift_knn2 *knn, int nq, int32_t *good_idx, int32_t *n_good) {
+    if ((nq > 0 && (!knn || !good_idx)) || !n_good) return fail(SIFT_ERR_INVALID, "NULL argument");
+    double min_dist = 100;  // main.cpp:77
+    for (int i = 0; i < nq; i++) {
+        if (knn[i].i1 < 0) continue;
+        const double dist = std::sqrt((float)knn[i].d1);  // DMatch::distance is float
+        if (dist < min_dist) min_dist = dist;
+    }
+    int g = 0;
+    for (int i = 0; i < nq; i++) {
+        if (knn[i].i1 < 0) continue;
+        const float dist = std::sqrt((float)knn[i].d1);
+        if (dist < 3 * min_dist) good_idx[g++] = i;  // main.cpp:88
+    }
+    *n_good = g;
+    return SIFT_OK;
+}
+
+}  // extern "C"
