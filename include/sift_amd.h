@@ -100,6 +100,10 @@ int sift_batch_frames_device_ptr(sift_batch *b, void **dptr);
 /* Copy one host frame into slot `frame` (asynchronous on the context stream). */
 int sift_batch_upload_gray8(sift_batch *b, int frame, const uint8_t *gray, size_t stride);
 int sift_batch_upload_bgr8(sift_batch *b, int frame, const uint8_t *bgr, size_t stride);
+/* Make the next runs read their frames from a caller-owned device buffer laid
+ * out [n][h][w] bytes instead of the batch's own frame buffer (NULL restores
+ * the internal buffer).  The buffer must stay valid until the run completes. */
+int sift_batch_set_external_frames(sift_batch *b, const void *d_frames);
 /* Enqueue the whole of exec() (sift.cpp:67-98: gen_gaussian_images,
  * gen_dog_images, gen_scale_space_extrema, clean_keypoints, get_descriptors)
  * for frames [0, n_frames) on the context stream.  Asynchronous. */
@@ -128,12 +132,16 @@ int sift_batch_get_oriented(sift_batch *b, int frame, int capacity, sift_keypoin
 /* Per-kernel device time of one run, measured with HIP events on the context
  * stream around every launch (serialises the run; use for profiling only). */
 #define SIFT_STAGE_BASE 0       /* gray -> 2x upsample -> base blur (sift.cpp:40-42) */
-#define SIFT_STAGE_BLUR_DOG 1   /* GaussianBlur levels 1..5 + subtract + next-octave resize (sift.cpp:150-153,173) */
-#define SIFT_STAGE_EXTREMA 2    /* 3x3x3 scan (sift.cpp:227-281) */
-#define SIFT_STAGE_LOCALIZE 3   /* localize_extrema + get_keypoint_orientations (sift.cpp:312-448) */
-#define SIFT_STAGE_CLEAN 4      /* clean_keypoints (sift.cpp:202-225) */
-#define SIFT_STAGE_DESCRIPTOR 5 /* get_descriptors (sift.cpp:450-584) */
-#define SIFT_STAGE_COUNT 6
+#define SIFT_STAGE_BLUR_L1 1    /* GaussianBlur level 1..5 + subtract (+ next-octave resize at level 3), */
+#define SIFT_STAGE_BLUR_L2 2    /* one stage per level = per tap count 11, 13, 17, 21, 27                */
+#define SIFT_STAGE_BLUR_L3 3    /* (sift.cpp:150-153, :173)                                              */
+#define SIFT_STAGE_BLUR_L4 4
+#define SIFT_STAGE_BLUR_L5 5
+#define SIFT_STAGE_EXTREMA 6    /* 3x3x3 scan (sift.cpp:227-281) */
+#define SIFT_STAGE_LOCALIZE 7   /* localize_extrema + get_keypoint_orientations (sift.cpp:312-448) */
+#define SIFT_STAGE_CLEAN 8      /* clean_keypoints (sift.cpp:202-225) */
+#define SIFT_STAGE_DESCRIPTOR 9 /* get_descriptors (sift.cpp:450-584) */
+#define SIFT_STAGE_COUNT 10
 typedef struct sift_stage_times {
     double ms[SIFT_STAGE_COUNT];    /* summed kernel time per stage */
     int32_t launches[SIFT_STAGE_COUNT];

@@ -21,7 +21,8 @@ SIFT_ERR_NOT_INTEGRAL = -4
 LEVEL_GAUSS = 0
 LEVEL_DOG = 1
 
-STAGE_NAMES = ("base", "blur_dog", "extrema", "localize_orient", "clean", "descriptor")
+STAGE_NAMES = ("base", "blur_l1", "blur_l2", "blur_l3", "blur_l4", "blur_l5", "extrema", "localize_orient", "clean",
+               "descriptor")
 
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -35,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "sift_last_error", "sift_device_count", "sift_ctx_create", "sift_ctx_destroy", "sift_ctx_stream",
     "sift_ctx_synchronize", "sift_num_octaves", "sift_octave_dims", "sift_extract_gray8", "sift_extract_bgr8",
     "sift_result_free", "sift_result_get_f32", "sift_batch_create", "sift_batch_destroy",
-    "sift_batch_frames_device_ptr", "sift_batch_upload_gray8", "sift_batch_upload_bgr8", "sift_batch_run",
+    "sift_batch_frames_device_ptr", "sift_batch_set_external_frames", "sift_batch_upload_gray8", "sift_batch_upload_bgr8", "sift_batch_run",
     "sift_batch_counts", "sift_batch_download", "sift_batch_result_device_ptrs", "sift_batch_get_level",
     "sift_batch_get_candidates", "sift_batch_get_oriented", "sift_batch_run_profiled", "sift_knn2_u8",
     "sift_knn2_f32", "sift_knn2_device", "sift_knn2_merge_device", "sift_match_min_dist_filter",
@@ -60,7 +61,7 @@ class _Result(C.Structure):
 
 
 class _StageTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int32 * 6)]
+    _fields_ = [("ms", C.c_double * 10), ("launches", C.c_int32 * 10)]
 
 
 _lib = None
@@ -92,6 +93,7 @@ def lib():
     L.sift_batch_create.argtypes = [vp, ci, ci, ci, ci, pvp]
     L.sift_batch_destroy.argtypes = [vp]
     L.sift_batch_frames_device_ptr.argtypes = [vp, pvp]
+    L.sift_batch_set_external_frames.argtypes = [vp, vp]
     L.sift_batch_upload_gray8.argtypes = [vp, ci, vp, sz]
     L.sift_batch_upload_bgr8.argtypes = [vp, ci, vp, sz]
     L.sift_batch_run.argtypes = [vp, ci]
@@ -267,6 +269,10 @@ class Batch:
         _check(lib().sift_batch_frames_device_ptr(self._h, C.byref(p)))
         return p.value
 
+    def set_external_frames(self, device_ptr):
+        """Read frames from a caller-owned device buffer [n][h][w] uint8 (None restores the internal one)."""
+        _check(lib().sift_batch_set_external_frames(self._h, device_ptr))
+
     def upload(self, frame, image):
         image = np.ascontiguousarray(image, np.uint8)
         if image.ndim == 2:
@@ -282,7 +288,7 @@ class Batch:
     def run_profiled(self, n_frames):
         t = _StageTimes()
         _check(lib().sift_batch_run_profiled(self._h, n_frames, C.byref(t)))
-        return {STAGE_NAMES[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(6)}
+        return {STAGE_NAMES[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(STAGE_NAMES))}
 
     def counts(self, n_frames):
         out = np.zeros(n_frames, COUNTS_DTYPE)

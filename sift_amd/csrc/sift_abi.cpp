@@ -81,6 +81,7 @@ struct sift_batch {
     int w = 0, h = 0, max_frames = 0;
     Pyramid pyr{};
     uint8_t *d_frames = nullptr;
+    const uint8_t *d_ext_frames = nullptr;  // caller-owned frames, if set
     uint8_t *d_bgr = nullptr;  // one frame of BGR staging, allocated on first use
     Candidate *d_cand = nullptr;
     int cand_cap = 0;
@@ -275,6 +276,12 @@ int sift_batch_frames_device_ptr(sift_batch *b, void **dptr) {
     return SIFT_OK;
 }
 
+int sift_batch_set_external_frames(sift_batch *b, const void *d_frames) {
+    if (!b) return fail(SIFT_ERR_INVALID, "batch is NULL");
+    b->d_ext_frames = (const uint8_t *)d_frames;
+    return SIFT_OK;
+}
+
 int sift_batch_upload_gray8(sift_batch *b, int frame, const uint8_t *gray, size_t stride) {
     if (!b || !gray) return fail(SIFT_ERR_INVALID, "NULL argument");
     if (frame < 0 || frame >= b->max_frames) return fail(SIFT_ERR_INVALID, "frame index out of range");
@@ -342,10 +349,11 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
         call;                                                           \
         if (tm.end()) return fail(SIFT_ERR_HIP, "hipEventRecord");      \
     } while (0)
-    TIMED(SIFT_STAGE_BASE, launch_base(st, b->d_frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
+    const uint8_t *frames = b->d_ext_frames ? b->d_ext_frames : b->d_frames;
+    TIMED(SIFT_STAGE_BASE, launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
     for (int o = 0; o < b->pyr.octaves; o++)
         for (int lvl = 1; lvl < IMAGES; lvl++)
-            TIMED(SIFT_STAGE_BLUR_DOG, launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
+            TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
     for (int o = 0; o < b->pyr.octaves; o++)
         TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
     TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_oriented, b->kp_cap,
