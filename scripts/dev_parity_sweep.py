@@ -1,0 +1,27 @@
+"""Sweep of synthetic frames: exact-equality statistics GPU vs oracle."""
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+import sift_amd as S
+from oracle import oracle as O
+ctx = S.Context(0)
+tot = dict(kp=0, angle=0, desc_rows=0, frames=0, count_mismatch=0)
+for (w, h, seed, nf) in [(1920, 1080, 1, 6), (960, 540, 1, 6), (640, 480, 9, 8)]:
+    for f in range(nf):
+        img = S.synth_dead_leaves(seed, f, w, h)
+        o = O.OracleSift(img).exec(threads=16, blur_threads=16)
+        kp, desc, info = ctx.extract(img)
+        okp, od = o.keypoints(), o.descriptors()
+        tot['frames'] += 1
+        if len(kp) != len(okp):
+            tot['count_mismatch'] += 1
+            print('COUNT MISMATCH', w, h, seed, f, len(kp), len(okp))
+            continue
+        for fld in ('x', 'y', 'size', 'response', 'octave'):
+            assert np.array_equal(kp[fld], okp[fld]), fld
+        na = int((kp['angle'] != okp['angle']).sum())
+        nd = int((np.abs(desc - od).max(1) > 0).sum())
+        tot['kp'] += len(kp); tot['angle'] += na; tot['desc_rows'] += nd
+        if na or nd:
+            print(w, h, seed, f, 'angle mismatches', na, 'max', np.abs(kp['angle'].astype(np.float64) - okp['angle']).max(), 'desc rows', nd)
+print(tot)

@@ -67,6 +67,25 @@ class _StageTimes(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own copy of the HIP runtime under the same
+    soname (libamdhip64.so.7) as the system one that libsift_amd.so links.  A
+    process that initialises both copies loses the GPU in the second one, so
+    when torch is installed its copy is loaded first and the dynamic linker
+    then binds libsift_amd.so to it: one runtime per process whatever the
+    import order.  Without torch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libsift_amd.so; raises if it has not been built."""
     global _lib
@@ -74,6 +93,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SiftError(SIFT_ERR_INVALID, "%s is missing: build it with `make -C sift_amd/csrc`" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, ci, sz, u64, i64 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_int64
     pvp = C.POINTER(C.c_void_p)

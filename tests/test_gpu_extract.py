@@ -1,0 +1,207 @@
+"""GPU parity tests of the extraction path: the HIP engine, called through the C
+ABI, against the CPU oracle and the committed golden vectors.
+
+Bar (stated once, used everywhere below):
+  * pyramid and DoG images, candidate sets, keypoint count, and the keypoint
+    fields x, y, size, response, octave: bit-exact (same IEEE operations in the
+    same order on both sides);
+  * angle: |diff| <= 1e-3 degrees (orientation histograms are summed in a
+    different, fixed, order on the GPU and libm/ocml differ by an ulp);
+  * descriptors: integer-exact for >= 99.9 % of keypoints, never off by more
+    than 1 in any bin (a rounding flip of round(512*v), sift.cpp:570).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def check_keypoints(kp, desc, okp, odesc):
+    assert len(kp) == len(okp)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kp[f], okp[f]), f
+    if len(kp):
+        assert np.abs(kp["angle"].astype(np.float64) - okp["angle"]).max() <= 1e-3
+        dd = np.abs(desc.astype(np.int32) - odesc.astype(np.int32))
+        assert dd.max() <= 1
+        assert (dd.max(axis=1) > 0).mean() <= 1e-3
+
+
+def sorted_quads(c):
+    return c[np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))]
+
+
+def oracle_quads(o):
+    c = o.candidates()
+    return np.stack([c["oct"], c["img"], c["i"], c["j"]], 1).astype(np.int32)
+
+
+def run_both(sift_lib, ctx, oracle, gray, check_pyramid=True):
+    h, w = gray.shape
+    o = oracle.OracleSift(gray).exec(threads=8, blur_threads=8)
+    b = ctx.batch(w, h, 1)
+    try:
+        b.upload(0, gray)
+        b.run(1)
+        cnt = b.counts(1)[0]
+        assert b.octaves == o.octaves
+        if check_pyramid:
+            for oc in range(o.octaves):
+                assert sift_lib.octave_dims(w, h, oc) == o.level_dims(oc)
+                for lvl in range(6):
+                    assert np.array_equal(b.level(0, oc, lvl, sift_lib.LEVEL_GAUSS), o.gauss(oc, lvl)), (oc, lvl)
+                for lvl in range(5):
+                    assert np.array_equal(b.level(0, oc, lvl, sift_lib.LEVEL_DOG), o.dog(oc, lvl)), (oc, lvl)
+        assert np.array_equal(sorted_quads(b.candidates(0)), oracle_quads(o))
+        st = o.stats()
+        assert cnt["candidates"] == int(st["candidates"].sum())
+        assert cnt["oriented"] == int(st["oriented"].sum())
+        kp, desc = b.download(0)
+        check_keypoints(kp, desc, o.keypoints(), o.descriptors())
+        return kp, desc, o
+    finally:
+        b.close()
+
+
+def test_lenna_full_parity(sift_lib, ctx, oracle, lenna_bgr, known):
+    gray = oracle.bgr_to_gray(lenna_bgr)
+    kp, desc, o = run_both(sift_lib, ctx, oracle, gray)
+    assert len(kp) == known["lenna"]["final_keypoints"] == 1112      # README.md:353-354
+
+
+def test_lenna_rotated_full_parity(sift_lib, ctx, oracle, lenna_rotated_bgr, known):
+    gray = oracle.bgr_to_gray(lenna_rotated_bgr)
+    kp, _, _ = run_both(sift_lib, ctx, oracle, gray)
+    assert len(kp) == known["lenna_rotated"]["final_keypoints"]
+
+
+@pytest.mark.parametrize("name", ["lenna", "lennarotated", "leaves_320x240_seed7"])
+def test_against_committed_golden_vectors(ctx, golden, name):
+    g = golden(name)
+    kp, desc, info = ctx.extract(g["gray"])
+    check_keypoints(kp, desc, g["keypoints"], g["descriptors"])
+    assert info["candidates"] == len(g["candidates"])
+
+
+def test_bgr_entry_point_matches_gray(ctx, oracle, lenna_bgr):
+    """sift_extract_bgr8 starts at cvtColor (sift.cpp:29): 15-bit integer coefficients."""
+    kp_b, d_b, _ = ctx.extract(lenna_bgr)
+    kp_g, d_g, _ = ctx.extract(oracle.bgr_to_gray(lenna_bgr))
+    assert np.array_equal(kp_b, kp_g) and np.array_equal(d_b, d_g)
+
+
+@pytest.mark.parametrize("w,h,seed", [(333, 205, 11), (130, 67, 12), (64, 257, 13), (31, 45, 14), (12, 16, 15)])
+def test_ragged_sizes(sift_lib, ctx, oracle, w, h, seed):
+    """Odd sizes: round-half-to-even octave sizes, partial tiles, reflect-101 borders
+    wider than the image in the small octaves."""
+    run_both(sift_lib, ctx, oracle, sift_lib.synth_dead_leaves(seed, 0, w, h))
+
+
+def test_natural_crop_non_multiple_of_tile(sift_lib, ctx, oracle, lenna_bgr):
+    gray = oracle.bgr_to_gray(lenna_bgr)[37:37 + 301, 50:50 + 415].copy()
+    run_both(sift_lib, ctx, oracle, gray)
+
+
+def test_flat_image_has_no_keypoints(ctx):
+    kp, desc, info = ctx.extract(np.full((96, 128), 200, np.uint8))
+    assert len(kp) == 0 and desc.shape == (0, 128) and info["candidates"] == 0
+
+
+def test_plateau_extrema_are_kept(sift_lib, ctx, oracle):
+    """Non-strict comparisons (sift.cpp:275-276): exact plateaus qualify.  A frame
+    mirrored top-bottom has exactly symmetric column sums."""
+    half = sift_lib.synth_dead_leaves(21, 0, 160, 60)
+    img = np.vstack([half, half[::-1]])
+    run_both(sift_lib, ctx, oracle, img)
+
+
+def test_batch_equals_single_and_is_deterministic(sift_lib, ctx):
+    w, h, n = 320, 240, 5
+    frames = [sift_lib.synth_dead_leaves(7, i, w, h) for i in range(n)]
+    single = [ctx.extract(f) for f in frames]
+    b = ctx.batch(w, h, n)
+    for i, f in enumerate(frames):
+        b.upload(i, f)
+    b.run(n)
+    first = [b.download(i) for i in range(n)]
+    b.run(n)
+    second = [b.download(i) for i in range(n)]
+    b.close()
+    for i in range(n):
+        kp, desc = first[i]
+        assert np.array_equal(kp, single[i][0])
+        assert np.array_equal(desc, single[i][1].astype(np.uint8))
+        assert np.array_equal(kp, second[i][0]) and np.array_equal(desc, second[i][1])
+
+
+def test_keypoints_are_sorted_and_unique_like_the_reference(ctx, golden):
+    kp, _, _ = ctx.extract(golden("lenna")["gray"])
+    # comparator of sift.cpp:204-213 (coordinates already halved, which preserves order)
+    key = list(zip(kp["x"], kp["y"], -kp["size"], kp["angle"], -kp["response"], -kp["octave"]))
+    assert key == sorted(key)
+    # std::unique predicate of sift.cpp:214-217 against the previous kept element
+    for a, b in zip(kp[:-1], kp[1:]):
+        assert abs(2 * a["x"] - 2 * b["x"]) > 1e-4 or abs(2 * a["size"] - 2 * b["size"]) > 1e-4 or \
+            abs(a["angle"] - b["angle"]) > 1e-4
+
+
+def test_capacity_overflow_is_reported(sift_lib, ctx, golden):
+    g = golden("leaves_320x240_seed7")
+    b = ctx.batch(320, 240, 1, 16)
+    b.upload(0, g["gray"])
+    b.run(1)
+    with pytest.raises(sift_lib.SiftError) as e:
+        b.counts(1)
+    assert e.value.code == sift_lib.api.SIFT_ERR_OVERFLOW
+    b.close()
+
+
+def test_get_returns_float_copy(sift_lib, ctx, golden):
+    """get() (sift.cpp:103-112) narrows the descriptors to float32."""
+    import ctypes as C
+    g = golden("leaves_320x240_seed7")
+    L = sift_lib.lib()
+    res = sift_lib.api._Result()
+    gray = np.ascontiguousarray(g["gray"])
+    assert L.sift_extract_gray8(ctx._h, gray.ctypes.data, 320, 240, 320, C.byref(res)) == 0
+    out = np.zeros((res.n, 128), np.float32)
+    assert L.sift_result_get_f32(C.byref(res), out.ctypes.data) == 0
+    L.sift_result_free(C.byref(res))
+    assert np.array_equal(out, g["descriptors"].astype(np.float32))
+
+
+def test_1080p_frame_against_oracle(sift_lib, ctx, oracle, known):
+    """BASELINE config 3 frame 0 at full size: candidates, keypoints and descriptors."""
+    img = sift_lib.synth_dead_leaves(1, 0, 1920, 1080)
+    kp, desc, o = run_both(sift_lib, ctx, oracle, img, check_pyramid=False)
+    k = known["dead_leaves_1920x1080_seed1_frame0"]
+    assert len(kp) == k["final_keypoints"]
+    assert int(o.stats()["candidates"].sum()) == k["candidates"]
+
+
+def test_1080p_pyramid_properties(sift_lib, ctx):
+    """Size-independent properties at full size: D[j-1] == G[j] - G[j-1], next octave
+    == even pixels of level 3, blur preserves the mean of a constant-extended image."""
+    img = sift_lib.synth_dead_leaves(1, 3, 1920, 1080)
+    b = ctx.batch(1920, 1080, 1)
+    b.upload(0, img)
+    b.run(1)
+    b.counts(1)
+    for oc in (0, 1, 4, 9):
+        g = [b.level(0, oc, l, sift_lib.LEVEL_GAUSS) for l in range(6)]
+        for l in range(5):
+            assert np.array_equal(b.level(0, oc, l, sift_lib.LEVEL_DOG), g[l + 1] - g[l])
+        if oc + 1 < b.octaves:
+            nxt = b.level(0, oc + 1, 0, sift_lib.LEVEL_GAUSS)
+            assert np.array_equal(nxt, g[3][::2, ::2][: nxt.shape[0], : nxt.shape[1]])
+        assert 0 <= g[5].min() and g[5].max() <= 255.0000001
+    b.close()
+
+
+def test_4k_frame_runs_and_matches_oracle_counts(sift_lib, ctx, oracle):
+    """BASELINE config 4 (3840x2160, 11 octaves, 7680x4320 base)."""
+    img = sift_lib.synth_dead_leaves(3, 0, 3840, 2160)
+    kp, desc, info = ctx.extract(img)
+    assert info["octaves"] == 11
+    o = oracle.OracleSift(img).exec(threads=16, blur_threads=16)
+    check_keypoints(kp, desc.astype(np.uint8), o.keypoints(), o.descriptors())

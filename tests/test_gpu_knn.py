@@ -1,0 +1,131 @@
+"""GPU parity tests of the matcher (int8 MFMA distance GEMM + fused top-2)
+against the exact CPU brute force.  Bar: indices, squared distances and the
+ratio-test bit identical for every query (integer arithmetic)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def check(ctx, oracle, q, t):
+    res, acc = ctx.knn2(q, t)
+    i1, d1, i2, d2, oacc = oracle.knn2_u8(q, t, threads=16)
+    assert np.array_equal(res["i1"], i1)
+    assert np.array_equal(res["i2"], i2)
+    assert np.array_equal(res["d1"], d1)
+    assert np.array_equal(res["d2"], d2)
+    assert np.array_equal(acc, oacc)
+    return res, acc
+
+
+def test_lenna_vs_rotated_matches(ctx, oracle, golden):
+    """BASELINE config 1: Lenna descriptors (queries) against LennaRotated (train)."""
+    q, t = golden("lenna")["descriptors"], golden("lennarotated")["descriptors"]
+    res, acc = check(ctx, oracle, q, t)
+    assert acc.sum() > 100
+    # live filter of main.cpp:77-91 from the same top-1
+    import sift_amd as S
+    good = S.min_dist_filter(res)
+    ref = oracle.min_dist_filter(np.sqrt(res["d1"].astype(np.float32)))
+    assert good.tolist() == ref.tolist()
+
+
+def test_float_entry_point(ctx, oracle, golden):
+    q, t = golden("lenna")["descriptors"], golden("lennarotated")["descriptors"]
+    res, acc = ctx.knn2(q.astype(np.float32), t.astype(np.float32))
+    i1, d1, i2, d2, oacc = oracle.knn2_f32(q.astype(np.float32), t.astype(np.float32), threads=16)
+    assert np.array_equal(res["i1"], i1) and np.array_equal(res["i2"], i2)
+    assert np.array_equal(res["d1"].astype(np.float32), d1) and np.array_equal(acc, oacc)
+
+
+def test_non_integral_descriptors_are_rejected(sift_lib, ctx):
+    q = np.full((4, 128), 0.5, np.float32)
+    with pytest.raises(sift_lib.SiftError) as e:
+        ctx.knn2(q, q)
+    assert e.value.code == sift_lib.api.SIFT_ERR_NOT_INTEGRAL
+    with pytest.raises(sift_lib.SiftError):
+        ctx.knn2(np.full((4, 128), 128, np.uint8), np.zeros((4, 128), np.uint8))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (3, 127), (255, 128), (256, 129), (257, 1000), (1000, 5), (5000, 33000)])
+def test_ragged_sizes(sift_lib, ctx, oracle, nq, nt):
+    t = sift_lib.synth_descriptors(5, nt)
+    q = sift_lib.synth_queries(6, t, nq)
+    check(ctx, oracle, q, t)
+
+
+def test_empty_train_set(ctx):
+    res, acc = ctx.knn2(np.zeros((7, 128), np.uint8), np.zeros((0, 128), np.uint8))
+    assert (res["i1"] == -1).all() and (res["i2"] == -1).all() and not acc.any()
+
+
+def test_ties_resolve_to_smaller_train_index(ctx, oracle):
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 103, (40, 128)).astype(np.uint8)
+    t = np.concatenate([base, base, base[::-1], base])      # every row appears 4 times
+    q = base[:17].copy()
+    res, _ = check(ctx, oracle, q, t)
+    assert (res["d1"] == 0).all() and (res["d2"] == 0).all()
+    assert res["i1"].tolist() == list(range(17))
+    assert res["i2"].tolist() == [i + 40 for i in range(17)]
+
+
+def test_extreme_values(ctx, oracle):
+    """All-127 and all-0 rows: largest magnitudes the int8 operands and int32 sums see."""
+    t = np.zeros((300, 128), np.uint8)
+    t[::2] = 127
+    t[5, :64] = 127
+    q = np.zeros((9, 128), np.uint8)
+    q[1::2] = 127
+    q[4, 64:] = 127
+    check(ctx, oracle, q, t)
+
+
+def test_sharded_train_set_merges_to_the_unsharded_result(sift_lib, ctx, oracle):
+    """Train set split into shards with index offsets, merged by the device merge
+    kernel: identical to one unsharded search whatever the shard count."""
+    import torch
+    nt, nq = 30000, 2000
+    t = sift_lib.synth_descriptors(5, nt)
+    q = sift_lib.synth_queries(6, t, nq)
+    full, facc = ctx.knn2(q, t)
+    d_q = torch.from_numpy(q).cuda()
+    for shards in (2, 3, 8):
+        bounds = [nt * s // shards for s in range(shards + 1)]
+        parts = torch.empty((shards, nq, 4), dtype=torch.int32, device="cuda")
+        keep = []
+        for s in range(shards):
+            d_t = torch.from_numpy(t[bounds[s]:bounds[s + 1]]).cuda()
+            keep.append(d_t)
+            ctx.knn2_device(d_q.data_ptr(), nq, d_t.data_ptr(), bounds[s + 1] - bounds[s], bounds[s],
+                            parts[s].data_ptr())
+        out = torch.empty((nq, 4), dtype=torch.int32, device="cuda")
+        acc = torch.empty(nq, dtype=torch.uint8, device="cuda")
+        ctx.knn2_merge_device(parts.data_ptr(), shards, nq, out.data_ptr(), acc.data_ptr())
+        ctx.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, 0], full["d1"]) and np.array_equal(got[:, 1], full["i1"])
+        assert np.array_equal(got[:, 2], full["d2"]) and np.array_equal(got[:, 3], full["i2"])
+        assert np.array_equal(acc.cpu().numpy(), facc)
+
+
+def test_large_scan_properties(sift_lib, ctx, oracle):
+    """BASELINE config 5 shape at a size the GPU finishes in a second (64k x 1M):
+    parity on a query subset against the CPU, and properties on all queries."""
+    nt, nq = 1 << 20, 1 << 16
+    t = sift_lib.synth_descriptors(5, nt)
+    q = sift_lib.synth_queries(6, t, nq)
+    res, acc = ctx.knn2(q, t)
+    sub = slice(0, 64)
+    i1, d1, i2, d2, oacc = oracle.knn2_u8(q[sub], t, threads=16)
+    assert np.array_equal(res["i1"][sub], i1) and np.array_equal(res["d1"][sub], d1)
+    assert np.array_equal(res["i2"][sub], i2) and np.array_equal(res["d2"][sub], d2)
+    assert np.array_equal(acc[sub], oacc)
+    # the reported distances are the true distances to the reported rows, d1 <= d2
+    for k in ("1", "2"):
+        rows = t[res["i" + k]].astype(np.int32)
+        dd = ((q.astype(np.int32) - rows) ** 2).sum(1)
+        assert np.array_equal(dd, res["d" + k])
+    assert (res["d1"] <= res["d2"]).all() and (res["i1"] != res["i2"]).all()
+    # even queries are noisy copies of a train row: they pass the ratio test
+    assert acc[0::2].mean() > 0.99 and acc[1::2].mean() < 0.05
