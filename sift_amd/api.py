@@ -22,7 +22,7 @@ LEVEL_GAUSS = 0
 LEVEL_DOG = 1
 
 STAGE_NAMES = ("base", "blur_l1", "blur_l2", "blur_l3", "blur_l4", "blur_l5", "extrema", "localize_orient", "clean",
-               "descriptor")
+               "descriptor", "gradient")
 
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -61,7 +61,7 @@ class _Result(C.Structure):
 
 
 class _StageTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 10), ("launches", C.c_int32 * 10)]
+    _fields_ = [("ms", C.c_double * 11), ("launches", C.c_int32 * 11)]
 
 
 _lib = None

@@ -36,14 +36,24 @@ struct Taps {
     double c[MAX_TAPS];
 };
 
+// Gradient of a Gaussian level at one pixel: magnitude and direction in degrees.
+struct alignas(16) Grad {
+    double mag;
+    double ori;
+};
+
 // One frame batch's scale space.  gauss[o] is [frame][IMAGES][h][w] doubles,
 // dog[o] is [frame][NDOG][h][w]; rows are tightly packed (pitch = w).
+// grad[o] is [frame][SCALES][h][w] Grad: the gradient planes of Gaussian
+// levels 1..SCALES, the only levels orientation and descriptor windows sample
+// (null for octaves too small to hold a keypoint).
 struct Pyramid {
     int octaves;
     int w[MAX_OCTAVES];
     int h[MAX_OCTAVES];
     double *gauss[MAX_OCTAVES];
     double *dog[MAX_OCTAVES];
+    Grad *grad[MAX_OCTAVES];
 };
 
 __host__ __device__ inline size_t gauss_off(const Pyramid &p, int o, int frame, int lvl) {
@@ -51,6 +61,10 @@ __host__ __device__ inline size_t gauss_off(const Pyramid &p, int o, int frame, 
 }
 __host__ __device__ inline size_t dog_off(const Pyramid &p, int o, int frame, int lvl) {
     return ((size_t)frame * NDOG + lvl) * (size_t)p.w[o] * p.h[o];
+}
+// layer = Gaussian level 1..SCALES
+__host__ __device__ inline size_t grad_off(const Pyramid &p, int o, int frame, int layer) {
+    return ((size_t)frame * SCALES + (layer - 1)) * (size_t)p.w[o] * p.h[o];
 }
 
 // Device keypoint record: a sift_keypoint padded to 32 bytes.

@@ -13,6 +13,9 @@ void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframe
 void launch_blur_dog(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps);
 void launch_bgr_to_gray(hipStream_t st, const uint8_t *bgr, uint8_t *gray, size_t npix);
 
+// kernels_gradient.hip
+void launch_gradients(hipStream_t st, const Pyramid &p, int oct, int nframes);
+
 // kernels_extrema.hip
 void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
                     FrameCounters *counters);

@@ -1,13 +1,25 @@
 // 4x4x8 descriptors: get_descriptors_parallel::operator() (sift.cpp:464-584).
 //
 // One 256-thread workgroup per keypoint; workgroups pull keypoints from a
-// per-frame cursor.  Threads sweep the (2*half_width+1)^2 window row-major (so
-// image reads are coalesced), and scatter each accepted sample's eight
-// trilinear contributions into a per-wave copy of the 6x6x8 tensor in LDS with
-// LDS double atomics.  The four copies are then summed in fixed order, the
-// inner 4x4x8 bins normalised, clipped at 0.2*norm, scaled by 512 and rounded
-// exactly as sift.cpp:557-573 does.  Output is one byte per bin (values 0..255;
-// at most 102 in practice).
+// per-frame cursor.  Each wave takes every fourth row of the
+// (2*half_width+1)^2 window.  For a row, the columns that can pass the
+// rotated-window test of sift.cpp:503 form an interval (two strips |a*j+b| < L
+// intersected); the wave sweeps only that interval, widened by one pixel, with
+// lanes on consecutive columns (coalesced reads), and every sample still takes
+// the exact test.  A sample's gradient magnitude and direction come from the
+// precomputed gradient plane of the keypoint's Gaussian level, and its
+// Gaussian weight exp(-(i^2+j^2)/(8 w^2)) is the product of two entries of a
+// per-keypoint table exp(-t^2/(8 w^2)) (the rotation preserves i^2+j^2), so
+// the loop has no transcendental.
+//
+// The eight trilinear contributions of a sample are scattered with LDS double
+// atomics.  Only the inner 4x4x8 bins are kept (the border ring of the 6x6x8
+// tensor is discarded by sift.cpp:557-563, so contributions to it are never
+// issued), and there is one 128-bin copy per (wave, lane & 7) so that
+// neighbouring pixels, which mostly share a bin, rarely collide.  The 32
+// copies are summed in fixed order, then normalised, clipped at 0.2*norm,
+// scaled by 512 and rounded exactly as sift.cpp:564-573 does.  Output is one
+// byte per bin (values 0..255; at most 102 in practice).
 #include "common.h"
 #include "kernels.h"
 
@@ -15,26 +27,44 @@ namespace sa {
 
 namespace {
 
-constexpr int DW = WINDOW_WIDTH + 2;       // 6
 constexpr int DBINS = 8;
-constexpr int TENSOR = DW * DW * DBINS;    // 288
+constexpr int INNER = WINDOW_WIDTH * WINDOW_WIDTH * DBINS;  // 128
 constexpr int NWAVES = 4;
+constexpr int COPIES_PER_WAVE = 8;
+constexpr int NCOPY = NWAVES * COPIES_PER_WAVE;
+
+// Intersect [lo, hi] with { j : |a*j + b| < L }.
+__device__ __forceinline__ void clip_strip(double a, double b, double L, double &lo, double &hi) {
+    if (fabs(a) < 1e-12) {
+        if (!(fabs(b) < L)) hi = lo - 4;  // empty
+        return;
+    }
+    double j1 = (-L - b) / a, j2 = (L - b) / a;
+    if (j1 > j2) {
+        const double t = j1;
+        j1 = j2;
+        j2 = t;
+    }
+    lo = fmax(lo, j1);
+    hi = fmin(hi, j2);
+}
 
 __global__ __launch_bounds__(256) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
                                                       const FrameCounters *__restrict__ counters,
                                                       int32_t *__restrict__ cursors, uint8_t *__restrict__ desc) {
-    __shared__ double tensor[NWAVES][TENSOR];
-    __shared__ double vals[128];
-    __shared__ double red[128];
+    __shared__ double tensor[NCOPY][INNER];
+    __shared__ double vals[INNER];
+    __shared__ double red[INNER];
+    __shared__ double wtab[256];
     __shared__ int s_idx;
     const int f = blockIdx.y;
     const int tid = threadIdx.x;
-    const int wv = tid >> 6;
+    const int wv = tid >> 6, lane = tid & 63;
     int n = counters[f].keypoints;
     if (n > kp_cap) n = kp_cap;
     for (;;) {
         if (tid == 0) s_idx = atomicAdd(&cursors[f], 1);
-        for (int t = tid; t < NWAVES * TENSOR; t += 256) (&tensor[0][0])[t] = 0.0;
+        for (int t = tid; t < NCOPY * INNER; t += 256) (&tensor[0][0])[t] = 0.0;
         __syncthreads();
         const int it = s_idx;
         if (it >= n) break;
@@ -45,7 +75,8 @@ __global__ __launch_bounds__(256) void k_descriptors(Pyramid p, const DevKeypoin
         const double scale = octave >= 0 ? (1.0 / double(1 << octave)) : (double(1 << -octave));
         const int po = octave + 1;
         const int width = p.w[po], height = p.h[po];
-        const double *image = p.gauss[po] + gauss_off(p, po, f, layer);  // sift.cpp:476
+        // gradients of gauss_images[octave + 1][layer] (sift.cpp:476)
+        const Grad *image = p.grad[po] + grad_off(p, po, f, layer);
         const int pt_x = (int)round(scale * kpt.x);
         const int pt_y = (int)round(scale * kpt.y);
         const double angle = 360 - kpt.angle;
@@ -57,72 +88,82 @@ __global__ __launch_bounds__(256) void k_descriptors(Pyramid p, const DevKeypoin
         const int half_width =
             (int)fmin(round(hist_width * (WINDOW_WIDTH + 1) / sqrt(2.0)),
                       sqrt((double)height * (double)height + (double)width * (double)width));  // sift.cpp:492-493
-        const int n1 = 2 * half_width + 1;
-        const int total = n1 * n1;
-        const float inv_n1 = 1.0f / (float)n1;
-        double *T = tensor[wv];
-        for (int s = tid; s < total; s += 256) {
-            int qi = (int)((float)s * inv_n1);
-            int rj = s - qi * n1;
-            if (rj < 0) { qi--; rj += n1; }
-            if (rj >= n1) { qi++; rj -= n1; }
-            const int i = qi - half_width, j = rj - half_width;
-            const double row_rotation = sinv * j + cosv * i;  // sift.cpp:497
-            const double col_rotation = sinv * i - cosv * j;  // sift.cpp:498
-            const double rr = row_rotation / hist_width, cr = col_rotation / hist_width;
-            const double bin_row = rr + 0.5 * (WINDOW_WIDTH - 1);
-            const double bin_col = cr + 0.5 * (WINDOW_WIDTH - 1);
-            if (!(bin_row > -1 && bin_col > -1 && bin_row < WINDOW_WIDTH && bin_col < WINDOW_WIDTH)) continue;
-            const int win_row = pt_y + i, win_col = pt_x + j;
-            if (!(win_row > 0 && win_col > 0 && win_row < height - 1 && win_col < width - 1)) continue;
-            const double *q = image + (size_t)win_row * width + win_col;
-            const double dx = q[1] - q[-1];
-            const double dy = q[-width] - q[width];
-            const double mag = sqrt(dx * dx + dy * dy);
-            const double orient = (atan2(dy, dx) * 180) / PI;  // |.| <= 180, so fmod(.,360) is the identity
-            const double exponent = rr * rr + cr * cr;
-            const double weight = exp(weight_multiplier * exponent);
-            const double magnitude = mag * weight;
-            const double orientation = (orient - angle) * bins_per_degree;  // sift.cpp:519
-            const int row_bin = (int)floor(bin_row);
-            const int col_bin = (int)floor(bin_col);
-            int orient_bin = (int)floor(orientation);
-            const double row_bin_pr = bin_row - row_bin;
-            const double col_bin_pr = bin_col - col_bin;
-            const double orient_bin_pr = orientation - orient_bin;
-            if (orient_bin < 0) orient_bin += DBINS;
-            if (orient_bin >= DBINS) orient_bin -= DBINS;
+        const double inv_hw = 1.0 / hist_width;
+        const double wscale = weight_multiplier * inv_hw * inv_hw;
+        const bool use_tab = half_width < 256;
+        if (use_tab)
+            for (int t = tid; t <= half_width; t += 256) wtab[t] = exp(wscale * (double)(t * t));
+        __syncthreads();
+        double *T = tensor[wv * COPIES_PER_WAVE + (lane & (COPIES_PER_WAVE - 1))];
+        // bin in (-1, 4)  <=>  |rot / hist_width| < 2.5
+        const double L = 0.5 * (WINDOW_WIDTH + 1) * hist_width;
+        // image bounds on the column: 0 < pt_x + j < width - 1 (sift.cpp:506)
+        const int jmin = max(-half_width, 1 - pt_x), jmax = min(half_width, width - 2 - pt_x);
+        for (int i = -half_width + wv; i <= half_width; i += NWAVES) {
+            const int win_row = pt_y + i;
+            if (!(win_row > 0 && win_row < height - 1)) continue;
+            const double ci = cosv * i, si = sinv * i;
+            double lo = jmin, hi = jmax;
+            clip_strip(sinv, ci, L, lo, hi);    // |sin*j + cos*i| < L
+            clip_strip(-cosv, si, L, lo, hi);   // |sin*i - cos*j| < L
+            if (!(hi >= lo - 2)) continue;
+            const int jlo = max(jmin, (int)floor(lo) - 1), jhi = min(jmax, (int)ceil(hi) + 1);
+            const double wrow = use_tab ? wtab[abs(i)] : 0.0;
+            const Grad *img_row = image + (size_t)win_row * width + pt_x;
+            for (int j = jlo + lane; j <= jhi; j += 64) {
+                const double row_rotation = sinv * j + ci;  // sift.cpp:497
+                const double col_rotation = si - cosv * j;  // sift.cpp:498
+                const double rr = row_rotation * inv_hw, cr = col_rotation * inv_hw;
+                const double bin_row = rr + 0.5 * (WINDOW_WIDTH - 1);
+                const double bin_col = cr + 0.5 * (WINDOW_WIDTH - 1);
+                if (!(bin_row > -1 && bin_col > -1 && bin_row < WINDOW_WIDTH && bin_col < WINDOW_WIDTH)) continue;
+                const Grad g = img_row[j];  // sift.cpp:507-510
+                const double weight = use_tab ? wrow * wtab[abs(j)] : exp(wscale * (double)(i * i + j * j));
+                const double magnitude = g.mag * weight;                       // sift.cpp:512-518
+                const double orientation = (g.ori - angle) * bins_per_degree;  // sift.cpp:519
+                const int row_bin = (int)floor(bin_row);
+                const int col_bin = (int)floor(bin_col);
+                int orient_bin = (int)floor(orientation);
+                const double row_bin_pr = bin_row - row_bin;
+                const double col_bin_pr = bin_col - col_bin;
+                const double orient_bin_pr = orientation - orient_bin;
+                if (orient_bin < 0) orient_bin += DBINS;
+                if (orient_bin >= DBINS) orient_bin -= DBINS;
 #pragma unroll
-            for (int a = 0; a < 2; a++)
+                for (int a = 0; a < 2; a++)
 #pragma unroll
-                for (int b = 0; b < 2; b++)
+                    for (int b = 0; b < 2; b++) {
+                        // tensor cell (row_bin+1+a, col_bin+1+b) of the 6x6 grid; inner cells are 1..4
+                        const int ri = row_bin + a, cj = col_bin + b;
+                        if ((unsigned)ri < (unsigned)WINDOW_WIDTH && (unsigned)cj < (unsigned)WINDOW_WIDTH) {
 #pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        double c = magnitude;
-                        c *= (!a ? (1 - row_bin_pr) : (row_bin_pr));
-                        c *= (!b ? (1 - col_bin_pr) : (col_bin_pr));
-                        c *= (!k ? (1 - orient_bin_pr) : (orient_bin_pr));
-                        const int ob = ((orient_bin + k) % DBINS + DBINS) % DBINS;
-                        atomicAdd(&T[((row_bin + 1 + a) * DW + (col_bin + 1 + b)) * DBINS + ob], c);
+                            for (int k = 0; k < 2; k++) {
+                                double c = magnitude;
+                                c *= (!a ? (1 - row_bin_pr) : (row_bin_pr));
+                                c *= (!b ? (1 - col_bin_pr) : (col_bin_pr));
+                                c *= (!k ? (1 - orient_bin_pr) : (orient_bin_pr));
+                                const int ob = ((orient_bin + k) % DBINS + DBINS) % DBINS;
+                                atomicAdd(&T[(ri * WINDOW_WIDTH + cj) * DBINS + ob], c);
+                            }
+                        }
                     }
+            }
         }
         __syncthreads();
-        // inner 4x4x8 bins (sift.cpp:557-563), wave copies summed in fixed order
-        if (tid < 128) {
-            const int i = tid >> 5, j = (tid >> 3) & 3, k = tid & 7;
-            const int o = ((i + 1) * DW + (j + 1)) * DBINS + k;
-            double v = tensor[0][o];
-#pragma unroll
-            for (int c = 1; c < NWAVES; c++) v += tensor[c][o];
+        // inner 4x4x8 bins (sift.cpp:557-563), copies summed in fixed order
+        if (tid < INNER) {
+            double v = tensor[0][tid];
+#pragma unroll 8
+            for (int c = 1; c < NCOPY; c++) v += tensor[c][tid];
             vals[tid] = v;
             red[tid] = v * v;
         }
         __syncthreads();
-        for (int sft = 64; sft > 0; sft >>= 1) {
+        for (int sft = INNER / 2; sft > 0; sft >>= 1) {
             if (tid < sft) red[tid] += red[tid + sft];
             __syncthreads();
         }
-        if (tid < 128) {
+        if (tid < INNER) {
             const double norm = sqrt(red[0]);            // sift.cpp:564-565
             const double thresh = norm * DESCRIPTOR_MAX;  // sift.cpp:566
             double I = vals[tid];

@@ -7,7 +7,6 @@
 // so localisation is bit-reproducible against a CPU evaluation; the
 // orientation histogram is summed per lane and combined in a fixed tree order,
 // so it is deterministic run to run.
-#include "angle_table.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -216,38 +215,6 @@ __device__ int localize(const Pyramid &p, int f, int oct, int img, int i, int j,
     return img;
 }
 
-// Histogram bin of a gradient direction: round(atan2(dy,dx) in degrees * 36/360)
-// mod 36 (sift.cpp:415-416).  Nearest-bin rounding is discontinuous at the 36
-// boundaries (5 + 10 m degrees), and images with exact diagonal symmetry put
-// strong gradients within an ulp of them, where the last bit of atan2 picks
-// the bin.  Host libm's atan2 is correctly rounded there; the device library's
-// is good to an ulp or two.  So when the fast result lands within 1e-9 bins of
-// a boundary, the angle is recomputed as boundary + atan(cross/dot) against a
-// double-double table of the boundary directions, which rounds correctly, and
-// the same double operations are then applied to it.
-__device__ __forceinline__ int orientation_index(double dy, double dx) {
-    double a = atan2(dy, dx);
-    double orientation = (a * 180) / PI;
-    double v = (orientation * BINS) / 360;
-    const double fl = floor(v);
-    if (fabs(v - fl - 0.5) < 1e-9) {
-        const int m = (int)fl;
-        if (m >= -18 && m <= 17) {
-            const double *T = kBinBoundary[m + 18];
-            const double p1 = dy * T[2], e1 = fma(dy, T[2], -p1);  // dy*cos(b), exact as p1 + e1
-            const double p2 = dx * T[4], e2 = fma(dx, T[4], -p2);  // dx*sin(b)
-            // p1 and p2 agree to ~1e-10 here, so p1 - p2 is exact
-            const double cross = (p1 - p2) + ((e1 - e2) + (dy * T[3] - dx * T[5]));
-            const double dot = dx * T[2] + dy * T[4];
-            const double delta = cross / dot;  // |delta| < 1e-9: atan(delta) == delta to 1e-27
-            a = T[0] + (T[1] + delta);
-            orientation = (a * 180) / PI;
-            v = (orientation * BINS) / 360;
-        }
-    }
-    return ((int)round(v) % BINS + BINS) % BINS;
-}
-
 __device__ __forceinline__ double wave_sum_fixed(double v) {
     // xor butterfly: every lane adds the same pairs in the same order
 #pragma unroll
@@ -281,7 +248,7 @@ __global__ __launch_bounds__(64) void k_localize_orient(Pyramid p, const Candida
         if (layer <= 0) continue;
         const int oct = cd.oct;
         const int w = p.w[oct], h = p.h[oct];
-        const double *L = p.gauss[oct] + gauss_off(p, oct, f, layer);
+        const Grad *L = p.grad[oct] + grad_off(p, oct, f, layer);
         const int base_x = (int)round(kpt.x / double(1 << oct));  // sift.cpp:398
         const int base_y = (int)round(kpt.y / double(1 << oct));
         const double scale = SCALE_FACTOR * kpt.size / double(1 << (oct + 1));  // sift.cpp:401
@@ -300,12 +267,9 @@ __global__ __launch_bounds__(64) void k_localize_orient(Pyramid p, const Candida
             const int i = qi - radius, j = rj - radius;
             const int y = base_y + i, x = base_x + j;
             if (y > 0 && y < h - 1 && x > 0 && x < w - 1) {  // sift.cpp:407,409
-                const double *q = L + (size_t)y * w + x;
-                const double dx = q[1] - q[-1];
-                const double dy = q[-w] - q[w];
-                const double mag = sqrt(dx * dx + dy * dy);
-                const int index = orientation_index(dy, dx);  // sift.cpp:415-416
-                hist[index * 64 + lane] += exp(weight_factor * (i * i + j * j)) * mag;
+                const Grad g = L[(size_t)y * w + x];           // mag, direction (sift.cpp:410-415)
+                const int index = ((int)round((g.ori * BINS) / 360) % BINS + BINS) % BINS;  // sift.cpp:416
+                hist[index * 64 + lane] += exp(weight_factor * (i * i + j * j)) * g.mag;
             }
         }
         __syncthreads();

@@ -153,6 +153,144 @@ __global__ __launch_bounds__(NTHREADS) void k_base(const uint8_t *__restrict__ f
                    [=](int gx, int gy, double s, double) { out[(size_t)gy * w + gx] = s; });
 }
 
+
+// ---------------------------------------------------------------------------
+// Marching blur: a workgroup owns a 64-column strip and walks down it 32 rows
+// at a time.  Each step stages 32 new input rows (plus the horizontal halo) in
+// one of two LDS buffers, row-filters them into a ring of row-filtered rows
+// (also LDS) and then column-filters the 32 output rows whose 2R+1 supports
+// are now complete.  Every input row is read from HBM and row-filtered once
+// per strip (no vertical halo recompute); the un-filtered centre values the DoG
+// needs come from the two staging buffers, not from a second global read; the
+// next step's input is prefetched into registers while the current step
+// computes; every thread has exactly one row item and one column item per
+// step.  Rows above/below the image are the reflected rows, re-filtered.
+constexpr int MCH = 32;  // rows per step
+
+template <int R>
+struct MarchGeom {
+    static constexpr int COLS = TW + 2 * R;
+    static constexpr int PIN = COLS | 1;   // odd pitch: lane<->row reads are conflict-free
+    static constexpr int RING = MCH + 2 * R;
+    static constexpr int PR = TW + 1;      // odd pitch: lane<->row writes are conflict-free
+    static constexpr int NLOAD = (MCH * COLS + NTHREADS - 1) / NTHREADS;
+    static constexpr size_t LDS_BYTES = (2 * (size_t)MCH * PIN + (size_t)RING * PR) * sizeof(double);
+};
+
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restrict__ in, double *__restrict__ out,
+                                                          double *__restrict__ dog, double *__restrict__ next, int w,
+                                                          int h, int nw, int nh, size_t in_frame_stride,
+                                                          size_t dog_frame_stride, size_t next_frame_stride,
+                                                          int strip_h, Taps taps) {
+    using G = MarchGeom<R>;
+    static_assert(R < MCH, "the centre rows of one step lie in the last two staging buffers");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *ring = smem + 2 * MCH * G::PIN;
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * TW;
+    const int ys = blockIdx.y * strip_h;
+    const int ye = min(h, ys + strip_h);
+    const size_t f = blockIdx.z;
+    in += f * in_frame_stride;
+    out += f * in_frame_stride;
+    dog += f * dog_frame_stride;
+    double *nxt = next ? next + f * next_frame_stride : nullptr;
+    const int nsteps = (ye - ys + 2 * R + MCH - 1) / MCH;
+
+    // this thread's share of a 32 x COLS staging tile: fixed (row, column) per slot
+    int pf_row[G::NLOAD], pf_gx[G::NLOAD], pf_lds[G::NLOAD];
+#pragma unroll
+    for (int u = 0; u < G::NLOAD; u++) {
+        const int idx = tid + NTHREADS * u;
+        const int r = idx / G::COLS, c = idx % G::COLS;
+        pf_row[u] = idx < MCH * G::COLS ? r : -1;
+        pf_gx[u] = reflect101(tx0 - R + c, w);
+        pf_lds[u] = r * G::PIN + c;
+    }
+    double pf[G::NLOAD];
+    auto fetch = [&](int s) {
+        const int v0 = ys - R + MCH * s;
+#pragma unroll
+        for (int u = 0; u < G::NLOAD; u++) {
+            if (pf_row[u] >= 0) pf[u] = in[(size_t)reflect101(v0 + pf_row[u], h) * w + pf_gx[u]];
+        }
+    };
+
+    fetch(0);
+    for (int s = 0; s < nsteps; s++) {
+        double *s_in = smem + (s & 1) * (MCH * G::PIN);
+#pragma unroll
+        for (int u = 0; u < G::NLOAD; u++)
+            if (pf_row[u] >= 0) s_in[pf_lds[u]] = pf[u];
+        __syncthreads();  // staging tile complete; previous step's column pass is done with the ring
+        if (s + 1 < nsteps) fetch(s + 1);
+        {   // row pass: lane <-> row, 8 consecutive outputs per thread
+            const int row = tid & (MCH - 1), cx = tid / MCH;
+            const double *p = s_in + row * G::PIN + cx * CX;
+            double v[CX + 2 * R];
+#pragma unroll
+            for (int k = 0; k < CX + 2 * R; k++) v[k] = p[k];
+            double *q = ring + ((MCH * s + row) % G::RING) * G::PR + cx * CX;
+            // eight independent accumulation chains, advanced one tap at a time
+            double acc[CX];
+#pragma unroll
+            for (int m = 0; m < CX; m++) acc[m] = taps.c[0] * v[m];
+#pragma unroll
+            for (int t = 1; t <= 2 * R; t++) {
+#pragma unroll
+                for (int m = 0; m < CX; m++) acc[m] += taps.c[t] * v[m + t];
+            }
+#pragma unroll
+            for (int m = 0; m < CX; m++) q[m] = acc[m];
+        }
+        __syncthreads();
+        {   // column pass: lane <-> column, 8 consecutive output rows per thread
+            const int x = tid & (TW - 1), cy = tid / TW;
+            const int rel0 = MCH * s + cy * CY - R;  // strip-relative index of the first output row
+            const int y0 = ys - R + rel0;            // its image row
+            const int gx = tx0 + x;
+            if (y0 + CY > ys && y0 < ye && gx < w) {
+                double v[CY + 2 * R];
+                int slot = (rel0 - R + 8 * G::RING) % G::RING;
+#pragma unroll
+                for (int k = 0; k < CY + 2 * R; k++) {
+                    v[k] = ring[slot * G::PR + x];
+                    slot = slot + 1 == G::RING ? 0 : slot + 1;
+                }
+                // un-filtered centres: strip-relative row rel was staged in step rel / 32
+                double centre[CY];
+#pragma unroll
+                for (int m = 0; m < CY; m++) {
+                    const int rel = rel0 + m;
+                    centre[m] = rel >= 0 ? smem[((rel / MCH) & 1) * (MCH * G::PIN) + (rel % MCH) * G::PIN + x + R] : 0.0;
+                }
+                double acc[CY];
+#pragma unroll
+                for (int m = 0; m < CY; m++) acc[m] = taps.c[R] * v[m + R];
+#pragma unroll
+                for (int t = 1; t <= R; t++) {
+#pragma unroll
+                    for (int m = 0; m < CY; m++) acc[m] += taps.c[R + t] * (v[m + R + t] + v[m + R - t]);
+                }
+#pragma unroll
+                for (int m = 0; m < CY; m++) {
+                    const int y = y0 + m;
+                    if (y >= ys && y < ye) {
+                        const size_t o = (size_t)y * w + gx;
+                        out[o] = acc[m];
+                        dog[o] = acc[m] - centre[m];
+                        if (nxt && !((gx | y) & 1)) {
+                            const int hx = gx >> 1, hy = y >> 1;
+                            if (hx < nw && hy < nh) nxt[(size_t)hy * nw + hx] = acc[m];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int R>
 void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps) {
     const int w = p.w[oct], h = p.h[oct];
@@ -169,9 +307,18 @@ void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nfram
         nh = p.h[oct + 1];
         next_stride = (size_t)IMAGES * nw * nh;
     }
-    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, nframes);
-    hipLaunchKernelGGL(k_blur_dog<R>, grid, dim3(NTHREADS), TileGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h, nw,
-                       nh, (size_t)IMAGES * plane, (size_t)NDOG * plane, next_stride, taps);
+    // strips of 64 columns, cut vertically so that the launch has >= ~2048 workgroups
+    const int nx = (w + TW - 1) / TW;
+    int ny = (2048 + nx * nframes - 1) / (nx * nframes);
+    const int max_ny = (h + 4 * MCH - 1) / (4 * MCH);  // at least 128 rows per strip
+    if (ny > max_ny) ny = max_ny;
+    if (ny < 1) ny = 1;
+    int strip_h = (h + ny - 1) / ny;
+    strip_h = (strip_h + MCH - 1) / MCH * MCH;
+    ny = (h + strip_h - 1) / strip_h;
+    dim3 grid(nx, ny, nframes);
+    hipLaunchKernelGGL(k_blur_march<R>, grid, dim3(NTHREADS), MarchGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h,
+                       nw, nh, (size_t)IMAGES * plane, (size_t)NDOG * plane, next_stride, strip_h, taps);
 }
 
 // cvtColor(BGR2GRAY) on 8-bit data (sift.cpp:29): OpenCV 4.x integer formula
@@ -187,8 +334,8 @@ __global__ void k_bgr_to_gray(const uint8_t *__restrict__ bgr, uint8_t *__restri
 
 template <int R>
 int set_lds_attr() {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blur_dog<R>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileGeom<R>::LDS_BYTES);
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blur_march<R>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MarchGeom<R>::LDS_BYTES);
     return e1 == hipSuccess ? 0 : -1;
 }
 

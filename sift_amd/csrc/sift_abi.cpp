@@ -180,6 +180,7 @@ int sift_batch_destroy(sift_batch *b) {
     for (int o = 0; o < MAX_OCTAVES; o++) {
         if (b->pyr.gauss[o]) hipFree(b->pyr.gauss[o]);
         if (b->pyr.dog[o]) hipFree(b->pyr.dog[o]);
+        if (b->pyr.grad[o]) hipFree(b->pyr.grad[o]);
     }
     hipFree(b->d_frames);
     hipFree(b->d_bgr);
@@ -254,6 +255,10 @@ int sift_batch_create(sift_ctx *ctx, int w, int h, int max_frames, int max_keypo
             return cleanup(e, "hipMalloc(gauss)");
         if ((e = hipMalloc((void **)&b->pyr.dog[o], plane * NDOG * max_frames)) != hipSuccess)
             return cleanup(e, "hipMalloc(dog)");
+        // gradient planes only where the scan range is non-empty (sift.cpp:188, :233)
+        if (ow > 2 * BORDER && oh > 2 * BORDER &&
+            (e = hipMalloc((void **)&b->pyr.grad[o], (size_t)ow * oh * sizeof(Grad) * SCALES * max_frames)) != hipSuccess)
+            return cleanup(e, "hipMalloc(grad)");
     }
     const size_t F = (size_t)max_frames;
     if ((e = hipMalloc((void **)&b->d_frames, F * px)) != hipSuccess) return cleanup(e, "hipMalloc(frames)");
@@ -354,6 +359,8 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
     for (int o = 0; o < b->pyr.octaves; o++)
         for (int lvl = 1; lvl < IMAGES; lvl++)
             TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
+    for (int o = 0; o < b->pyr.octaves; o++)
+        if (b->pyr.grad[o]) TIMED(SIFT_STAGE_GRADIENT, launch_gradients(st, b->pyr, o, n));
     for (int o = 0; o < b->pyr.octaves; o++)
         TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
     TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_oriented, b->kp_cap,
