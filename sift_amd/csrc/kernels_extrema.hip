@@ -29,46 +29,86 @@ __device__ __forceinline__ int wave_append(bool flag, int32_t *counter) {
     return flag ? base + rank : -1;
 }
 
-// is_pixel_extremum (sift.cpp:264-281) for the three scanned layers of one pixel.
+// is_pixel_extremum (sift.cpp:264-281) for the three scanned layers.  A
+// workgroup stages a 64x16 pixel tile (plus a one-pixel halo) of all five DoG
+// levels in LDS, so every DoG value is read from HBM once; each thread then
+// tests four pixels in three layers against their 26 neighbours out of LDS.
+constexpr int EX_TW = 64, EX_TH = 16;
+
 __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
                                                   FrameCounters *__restrict__ counters) {
+    __shared__ double s[NDOG][EX_TH + 2][EX_TW + 2];
     const int w = p.w[oct], h = p.h[oct];
     const int f = blockIdx.z;
-    const int j = BORDER + blockIdx.x * 64 + (threadIdx.x & 63);
-    const int i = BORDER + blockIdx.y * 4 + (threadIdx.x >> 6);
-    const bool inside = (j < w - BORDER) && (i < h - BORDER);
+    const int x0 = BORDER + blockIdx.x * EX_TW, y0 = BORDER + blockIdx.y * EX_TH;
     const size_t plane = (size_t)w * h;
     const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
-    const double threshold = floor(0.5 * CONTRAST_THRESHOLD / SCALES * 255);  // sift.cpp:266
-    for (int img = 1; img <= SCALES; img++) {
-        bool is_ext = false;
-        if (inside) {
-            const double *Dc = D + (size_t)img * plane + (size_t)i * w + j;
-            const double c = *Dc;
-            if (fabs(c) > threshold) {  // sift.cpp:268
-                bool is_max = true, is_min = true;
+    const int x = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    {
+        // All loads of the tile are issued before the first LDS write, with row and
+        // column indices clamped into the image instead of branching: tested pixels
+        // lie BORDER pixels inside, so a clamped halo value is never compared.
+        constexpr int NR = (EX_TH + 2 + 3) / 4;  // tile rows per thread
+        const int gx = min(x0 - 1 + x, w - 1);
+        const int gx2 = min(x0 - 1 + EX_TW + (x & 1), w - 1);
+        double v[NDOG][NR], v2[NDOG][NR];
 #pragma unroll
-                for (int k = -1; k <= 1; k++) {
-                    const double *Dk = Dc + (ptrdiff_t)k * (ptrdiff_t)plane;
+        for (int lvl = 0; lvl < NDOG; lvl++)
 #pragma unroll
-                    for (int a = -1; a <= 1; a++)
-#pragma unroll
-                        for (int b = -1; b <= 1; b++) {
-                            const double v = Dk[a * w + b];
-                            is_max &= c >= v;
-                            is_min &= c <= v;
-                        }
-                }
-                is_ext = ((c < 0) & is_min) | ((c > 0) & is_max);  // sift.cpp:280
+            for (int k = 0; k < NR; k++) {
+                const int gy = min(y0 - 1 + min(ty + 4 * k, EX_TH + 1), h - 1);
+                const double *row = D + (size_t)lvl * plane + (size_t)gy * w;
+                v[lvl][k] = row[gx];
+                v2[lvl][k] = row[gx2];  // the two halo columns on the right (same cache line for all lanes)
             }
-        }
-        const int slot = wave_append(is_ext, &counters[f].candidates);
-        if (slot >= 0) {
-            if (slot < cand_cap) {
-                Candidate cd = {oct, img, i, j};
-                cand[(size_t)f * cand_cap + slot] = cd;
-            } else {
-                counters[f].overflow = 1;
+#pragma unroll
+        for (int lvl = 0; lvl < NDOG; lvl++)
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                const int r = ty + 4 * k;
+                if (r < EX_TH + 2) {
+                    s[lvl][r][x] = v[lvl][k];
+                    if (x < 2) s[lvl][r][EX_TW + x] = v2[lvl][k];
+                }
+            }
+    }
+    __syncthreads();
+    const double threshold = floor(0.5 * CONTRAST_THRESHOLD / SCALES * 255);  // sift.cpp:266
+    const int j = x0 + x;
+#pragma unroll
+    for (int q = 0; q < EX_TH / 4; q++) {
+        const int y = ty + 4 * q;
+        const int i = y0 + y;
+        const bool inside = (j < w - BORDER) && (i < h - BORDER);
+        for (int img = 1; img <= SCALES; img++) {
+            bool is_ext = false;
+            const double c = s[img][y + 1][x + 1];
+            if (inside && fabs(c) > threshold) {  // sift.cpp:268
+                // A negative centre must be a minimum, a positive one a maximum
+                // (sift.cpp:275-280; |c| > threshold so c != 0).  Flipping the sign
+                // bit of everything when c < 0 turns both cases into "c >= all".
+                const unsigned long long flip = c < 0 ? 0x8000000000000000ull : 0ull;
+                const double cf = __longlong_as_double(__double_as_longlong(c) ^ flip);
+                bool ok = true;
+#pragma unroll
+                for (int k = -1; k <= 1; k++)
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int b = 0; b < 3; b++) {
+                            const double v = s[img + k][y + a][x + b];
+                            ok &= cf >= __longlong_as_double(__double_as_longlong(v) ^ flip);
+                        }
+                is_ext = ok;
+            }
+            const int slot = wave_append(is_ext, &counters[f].candidates);
+            if (slot >= 0) {
+                if (slot < cand_cap) {
+                    Candidate cd = {oct, img, i, j};
+                    cand[(size_t)f * cand_cap + slot] = cd;
+                } else {
+                    counters[f].overflow = 1;
+                }
             }
         }
     }
@@ -319,7 +359,7 @@ void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Cand
                     FrameCounters *counters) {
     const int w = p.w[oct], h = p.h[oct];
     if (w <= 2 * BORDER || h <= 2 * BORDER) return;  // empty scan range (sift.cpp:188, :233)
-    dim3 grid((w - 2 * BORDER + 63) / 64, (h - 2 * BORDER + 3) / 4, nframes);
+    dim3 grid((w - 2 * BORDER + EX_TW - 1) / EX_TW, (h - 2 * BORDER + EX_TH - 1) / EX_TH, nframes);
     hipLaunchKernelGGL(k_extrema, grid, dim3(256), 0, st, p, oct, cand, cand_cap, counters);
 }
 

@@ -2,11 +2,22 @@
 //
 // Replaces gen_gaussian_images (sift.cpp:132-156), gen_dog_images
 // (sift.cpp:161-177) and the base-image part of the constructor
-// (sift.cpp:40-42).  Every blur is one launch: a workgroup stages an input tile
-// plus halo in LDS, filters rows into a second LDS tile and filters columns
-// straight to HBM, writing the blurred level, the DoG level (blurred minus
-// input, sift.cpp:173) and, for level 3, the nearest-neighbour half-size base of
-// the next octave (sift.cpp:152-153) in the same pass.
+// (sift.cpp:40-42).  Every blur is one launch that reads its input level once
+// and writes the blurred level, the DoG level (blurred minus input,
+// sift.cpp:173) and, for level 3, the nearest-neighbour half-size base of the
+// next octave (sift.cpp:152-153) in the same pass.
+//
+// Marching structure: a workgroup owns a 64-column strip and walks down it 32
+// rows at a time.  Each step stages 32 new input rows (plus the horizontal
+// halo) in one of two LDS buffers, row-filters them into a ring of
+// row-filtered rows (also LDS) and then column-filters the 32 output rows
+// whose 2R+1 supports are now complete.  Every input row is read from HBM and
+// row-filtered once per strip (no vertical halo recompute); the un-filtered
+// centre values the DoG needs come from the two staging buffers, not from a
+// second global read; the next step's input is prefetched into registers while
+// the current step computes; every thread has exactly one row item and one
+// column item per step.  Rows above/below the image are the reflected rows
+// (BORDER_REFLECT_101), re-filtered.
 //
 // Arithmetic order is fixed (and contraction is off for this file) so that
 // results are bit-identical to a scalar CPU evaluation of the same filter:
@@ -19,153 +30,11 @@ namespace sa {
 
 namespace {
 
-constexpr int TW = 64;   // tile width  (outputs)
-constexpr int TH = 32;   // tile height (outputs)
+constexpr int TW = 64;   // strip width (outputs)
+constexpr int MCH = 32;  // rows per step
 constexpr int CX = 8;    // consecutive outputs per thread in the row pass
 constexpr int CY = 8;    // consecutive outputs per thread in the column pass
 constexpr int NTHREADS = 256;
-
-template <int R>
-struct TileGeom {
-    static constexpr int ROWS = TH + 2 * R;
-    static constexpr int COLS = TW + 2 * R;
-    static constexpr int PIN = COLS | 1;  // odd pitches: lane<->row accesses hit distinct banks
-    static constexpr int PT = TW + 1;
-    static constexpr size_t LDS_BYTES = (size_t)ROWS * (PIN + PT) * sizeof(double);
-};
-
-// Row pass then column pass over the tile whose input (with halo) is in s_in.
-// store(gx, gy, blurred, centre_input) is called for every in-image output.
-template <int R, class Store>
-__device__ __forceinline__ void filter_tile(const Taps &taps, double *s_in, double *s_tmp, int tx0, int ty0, int w,
-                                            int h, Store store) {
-    using G = TileGeom<R>;
-    const int tid = threadIdx.x;
-    // rows: item -> (row, chunk of CX outputs); consecutive lanes take consecutive rows
-    for (int item = tid; item < G::ROWS * (TW / CX); item += NTHREADS) {
-        const int row = item % G::ROWS, cx = item / G::ROWS;
-        const double *p = s_in + row * G::PIN + cx * CX;
-        double v[CX + 2 * R];
-#pragma unroll
-        for (int k = 0; k < CX + 2 * R; k++) v[k] = p[k];
-        double *q = s_tmp + row * G::PT + cx * CX;
-#pragma unroll
-        for (int m = 0; m < CX; m++) {
-            double s = taps.c[0] * v[m];
-#pragma unroll
-            for (int t = 1; t <= 2 * R; t++) s += taps.c[t] * v[m + t];
-            q[m] = s;
-        }
-    }
-    __syncthreads();
-    // columns: one item per thread: column x, chunk of CY outputs
-    static_assert(TW * (TH / CY) == NTHREADS, "one column item per thread");
-    {
-        const int x = tid % TW, cy = tid / TW;
-        const double *p = s_tmp + (cy * CY) * G::PT + x;
-        double v[CY + 2 * R];
-#pragma unroll
-        for (int k = 0; k < CY + 2 * R; k++) v[k] = p[k * G::PT];
-        const int gx = tx0 + x;
-#pragma unroll
-        for (int m = 0; m < CY; m++) {
-            double s = taps.c[R] * v[m + R];
-#pragma unroll
-            for (int t = 1; t <= R; t++) s += taps.c[R + t] * (v[m + R + t] + v[m + R - t]);
-            const int gy = ty0 + cy * CY + m;
-            if (gx < w && gy < h) store(gx, gy, s, s_in[(cy * CY + m + R) * G::PIN + x + R]);
-        }
-    }
-}
-
-// One blur level of one octave for every frame of the batch (grid.z = frame).
-template <int R>
-__global__ __launch_bounds__(NTHREADS) void k_blur_dog(const double *__restrict__ in, double *__restrict__ out,
-                                                        double *__restrict__ dog, double *__restrict__ next, int w,
-                                                        int h, int nw, int nh, size_t in_frame_stride,
-                                                        size_t dog_frame_stride, size_t next_frame_stride,
-                                                        Taps taps) {
-    using G = TileGeom<R>;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *s_in = smem;
-    double *s_tmp = smem + G::ROWS * G::PIN;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const size_t f = blockIdx.z;
-    in += f * in_frame_stride;
-    out += f * in_frame_stride;
-    dog += f * dog_frame_stride;
-    const bool interior = tx0 >= R && ty0 >= R && tx0 + TW + R <= w && ty0 + TH + R <= h;
-    for (int idx = threadIdx.x; idx < G::ROWS * G::COLS; idx += NTHREADS) {
-        const int y = idx / G::COLS, x = idx % G::COLS;
-        int gy = ty0 - R + y, gx = tx0 - R + x;
-        if (!interior) {
-            gy = reflect101(gy, h);
-            gx = reflect101(gx, w);
-        }
-        s_in[y * G::PIN + x] = in[(size_t)gy * w + gx];
-    }
-    __syncthreads();
-    double *nxt = next ? next + f * next_frame_stride : nullptr;
-    filter_tile<R>(taps, s_in, s_tmp, tx0, ty0, w, h, [=](int gx, int gy, double s, double c) {
-        const size_t o = (size_t)gy * w + gx;
-        out[o] = s;
-        dog[o] = s - c;
-        if (nxt && !((gx | gy) & 1)) {
-            const int hx = gx >> 1, hy = gy >> 1;
-            if (hx < nw && hy < nh) nxt[(size_t)hy * nw + hx] = s;
-        }
-    });
-}
-
-// gray u8 -> double -> 2x bilinear upsample -> base blur, one launch.
-// The upsample is resize(INTER_LINEAR) to twice the size: source coordinate
-// (d+0.5)/2-0.5 clamped at the edges; 8-bit inputs make it exact in double.
-template <int R>
-__global__ __launch_bounds__(NTHREADS) void k_base(const uint8_t *__restrict__ frames, int W, int H,
-                                                    double *__restrict__ out, size_t out_frame_stride, Taps taps) {
-    using G = TileGeom<R>;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *s_in = smem;
-    double *s_tmp = smem + G::ROWS * G::PIN;
-    const int w = 2 * W, h = 2 * H;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const size_t f = blockIdx.z;
-    const uint8_t *src = frames + f * (size_t)W * H;
-    out += f * out_frame_stride;
-    for (int idx = threadIdx.x; idx < G::ROWS * G::COLS; idx += NTHREADS) {
-        const int y = idx / G::COLS, x = idx % G::COLS;
-        const int gy = reflect101(ty0 - R + y, h), gx = reflect101(tx0 - R + x, w);
-        // even d = 2k: 0.25*s[k-1] + 0.75*s[k]; odd d = 2k+1: 0.75*s[k] + 0.25*s[k+1]; clamped
-        int sx = (gx - 1) >> 1, sy = (gy - 1) >> 1;  // floor((d-1)/2)
-        double fx = (gx & 1) ? 0.25 : 0.75, fy = (gy & 1) ? 0.25 : 0.75;
-        if (sx < 0) { sx = 0; fx = 0; }
-        if (sx >= W - 1) { sx = W - 1; fx = 0; }
-        if (sy < 0) { sy = 0; fy = 0; }
-        if (sy >= H - 1) { sy = H - 1; fy = 0; }
-        const int sx1 = min(sx + 1, W - 1), sy1 = min(sy + 1, H - 1);
-        const double a = src[(size_t)sy * W + sx], b = src[(size_t)sy * W + sx1];
-        const double c = src[(size_t)sy1 * W + sx], d = src[(size_t)sy1 * W + sx1];
-        const double r0 = a * (1.0 - fx) + b * fx, r1 = c * (1.0 - fx) + d * fx;
-        s_in[y * G::PIN + x] = r0 * (1.0 - fy) + r1 * fy;
-    }
-    __syncthreads();
-    filter_tile<R>(taps, s_in, s_tmp, tx0, ty0, w, h,
-                   [=](int gx, int gy, double s, double) { out[(size_t)gy * w + gx] = s; });
-}
-
-
-// ---------------------------------------------------------------------------
-// Marching blur: a workgroup owns a 64-column strip and walks down it 32 rows
-// at a time.  Each step stages 32 new input rows (plus the horizontal halo) in
-// one of two LDS buffers, row-filters them into a ring of row-filtered rows
-// (also LDS) and then column-filters the 32 output rows whose 2R+1 supports
-// are now complete.  Every input row is read from HBM and row-filtered once
-// per strip (no vertical halo recompute); the un-filtered centre values the DoG
-// needs come from the two staging buffers, not from a second global read; the
-// next step's input is prefetched into registers while the current step
-// computes; every thread has exactly one row item and one column item per
-// step.  Rows above/below the image are the reflected rows, re-filtered.
-constexpr int MCH = 32;  // rows per step
 
 template <int R>
 struct MarchGeom {
@@ -177,25 +46,48 @@ struct MarchGeom {
     static constexpr size_t LDS_BYTES = (2 * (size_t)MCH * PIN + (size_t)RING * PR) * sizeof(double);
 };
 
-template <int R>
-__global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restrict__ in, double *__restrict__ out,
-                                                          double *__restrict__ dog, double *__restrict__ next, int w,
-                                                          int h, int nw, int nh, size_t in_frame_stride,
-                                                          size_t dog_frame_stride, size_t next_frame_stride,
-                                                          int strip_h, Taps taps) {
+// Source of the blur levels: the previous Gaussian level.
+struct LevelSource {
+    const double *in;
+    int w;
+    __device__ __forceinline__ double operator()(int gy, int gx) const { return in[(size_t)gy * w + gx]; }
+};
+
+// Source of the base blur: the 8-bit frame upsampled 2x on the fly.  This is
+// resize(INTER_LINEAR) to exactly twice the size (sift.cpp:40): source
+// coordinate (d+0.5)/2-0.5 clamped at the edges, i.e. even d = 2k takes
+// 0.25*s[k-1] + 0.75*s[k] and odd d = 2k+1 takes 0.75*s[k] + 0.25*s[k+1];
+// 8-bit inputs make every product and sum exact in double.
+struct UpsampleSource {
+    const uint8_t *src;
+    int W, H;
+    __device__ __forceinline__ double operator()(int gy, int gx) const {
+        int sx = (gx - 1) >> 1, sy = (gy - 1) >> 1;  // floor((d-1)/2)
+        double fx = (gx & 1) ? 0.25 : 0.75, fy = (gy & 1) ? 0.25 : 0.75;
+        if (sx < 0) { sx = 0; fx = 0; }
+        if (sx >= W - 1) { sx = W - 1; fx = 0; }
+        if (sy < 0) { sy = 0; fy = 0; }
+        if (sy >= H - 1) { sy = H - 1; fy = 0; }
+        const int sx1 = min(sx + 1, W - 1), sy1 = min(sy + 1, H - 1);
+        const double a = src[(size_t)sy * W + sx], b = src[(size_t)sy * W + sx1];
+        const double c = src[(size_t)sy1 * W + sx], d = src[(size_t)sy1 * W + sx1];
+        const double r0 = a * (1.0 - fx) + b * fx, r1 = c * (1.0 - fx) + d * fx;
+        return r0 * (1.0 - fy) + r1 * fy;
+    }
+};
+
+// grid: (strips, vertical segments, frames).  `dog` and `nxt` may be null.
+template <int R, class Source>
+__device__ __forceinline__ void march(const Source source, double *__restrict__ out, double *__restrict__ dog,
+                                      double *__restrict__ nxt, int w, int h, int nw, int nh, int strip_h,
+                                      const Taps &taps, double *smem) {
     using G = MarchGeom<R>;
     static_assert(R < MCH, "the centre rows of one step lie in the last two staging buffers");
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     double *ring = smem + 2 * MCH * G::PIN;
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * TW;
     const int ys = blockIdx.y * strip_h;
     const int ye = min(h, ys + strip_h);
-    const size_t f = blockIdx.z;
-    in += f * in_frame_stride;
-    out += f * in_frame_stride;
-    dog += f * dog_frame_stride;
-    double *nxt = next ? next + f * next_frame_stride : nullptr;
     const int nsteps = (ye - ys + 2 * R + MCH - 1) / MCH;
 
     // this thread's share of a 32 x COLS staging tile: fixed (row, column) per slot
@@ -213,7 +105,7 @@ __global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restric
         const int v0 = ys - R + MCH * s;
 #pragma unroll
         for (int u = 0; u < G::NLOAD; u++) {
-            if (pf_row[u] >= 0) pf[u] = in[(size_t)reflect101(v0 + pf_row[u], h) * w + pf_gx[u]];
+            if (pf_row[u] >= 0) pf[u] = source(reflect101(v0 + pf_row[u], h), pf_gx[u]);
         }
     };
 
@@ -263,7 +155,9 @@ __global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restric
 #pragma unroll
                 for (int m = 0; m < CY; m++) {
                     const int rel = rel0 + m;
-                    centre[m] = rel >= 0 ? smem[((rel / MCH) & 1) * (MCH * G::PIN) + (rel % MCH) * G::PIN + x + R] : 0.0;
+                    centre[m] = (dog && rel >= 0)
+                                    ? smem[((rel / MCH) & 1) * (MCH * G::PIN) + (rel % MCH) * G::PIN + x + R]
+                                    : 0.0;
                 }
                 double acc[CY];
 #pragma unroll
@@ -279,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restric
                     if (y >= ys && y < ye) {
                         const size_t o = (size_t)y * w + gx;
                         out[o] = acc[m];
-                        dog[o] = acc[m] - centre[m];
+                        if (dog) dog[o] = acc[m] - centre[m];
                         if (nxt && !((gx | y) & 1)) {
                             const int hx = gx >> 1, hy = y >> 1;
                             if (hx < nw && hy < nh) nxt[(size_t)hy * nw + hx] = acc[m];
@@ -289,6 +183,44 @@ __global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restric
             }
         }
     }
+}
+
+// One blur level of one octave for every frame of the batch.
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restrict__ in, double *__restrict__ out,
+                                                          double *__restrict__ dog, double *__restrict__ next, int w,
+                                                          int h, int nw, int nh, size_t in_frame_stride,
+                                                          size_t dog_frame_stride, size_t next_frame_stride,
+                                                          int strip_h, Taps taps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const size_t f = blockIdx.z;
+    const LevelSource source{in + f * in_frame_stride, w};
+    march<R>(source, out + f * in_frame_stride, dog + f * dog_frame_stride,
+             next ? next + f * next_frame_stride : nullptr, w, h, nw, nh, strip_h, taps, smem);
+}
+
+// gray u8 -> double -> 2x bilinear upsample -> base blur (sift.cpp:30, :40-42).
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void k_base_march(const uint8_t *__restrict__ frames, int W, int H,
+                                                          double *__restrict__ out, size_t out_frame_stride,
+                                                          int strip_h, Taps taps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const size_t f = blockIdx.z;
+    const UpsampleSource source{frames + f * (size_t)W * H, W, H};
+    march<R>(source, out + f * out_frame_stride, nullptr, nullptr, 2 * W, 2 * H, 0, 0, strip_h, taps, smem);
+}
+
+// strips of 64 columns, cut vertically so that the launch has >= ~2048 workgroups
+void strip_grid(int w, int h, int nframes, dim3 &grid, int &strip_h) {
+    const int nx = (w + TW - 1) / TW;
+    int ny = (2048 + nx * nframes - 1) / (nx * nframes);
+    const int max_ny = (h + 4 * MCH - 1) / (4 * MCH);  // at least 128 rows per strip
+    if (ny > max_ny) ny = max_ny;
+    if (ny < 1) ny = 1;
+    strip_h = (h + ny - 1) / ny;
+    strip_h = (strip_h + MCH - 1) / MCH * MCH;
+    ny = (h + strip_h - 1) / strip_h;
+    grid = dim3(nx, ny, nframes);
 }
 
 template <int R>
@@ -307,16 +239,9 @@ void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nfram
         nh = p.h[oct + 1];
         next_stride = (size_t)IMAGES * nw * nh;
     }
-    // strips of 64 columns, cut vertically so that the launch has >= ~2048 workgroups
-    const int nx = (w + TW - 1) / TW;
-    int ny = (2048 + nx * nframes - 1) / (nx * nframes);
-    const int max_ny = (h + 4 * MCH - 1) / (4 * MCH);  // at least 128 rows per strip
-    if (ny > max_ny) ny = max_ny;
-    if (ny < 1) ny = 1;
-    int strip_h = (h + ny - 1) / ny;
-    strip_h = (strip_h + MCH - 1) / MCH * MCH;
-    ny = (h + strip_h - 1) / strip_h;
-    dim3 grid(nx, ny, nframes);
+    dim3 grid;
+    int strip_h;
+    strip_grid(w, h, nframes, grid, strip_h);
     hipLaunchKernelGGL(k_blur_march<R>, grid, dim3(NTHREADS), MarchGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h,
                        nw, nh, (size_t)IMAGES * plane, (size_t)NDOG * plane, next_stride, strip_h, taps);
 }
@@ -348,8 +273,8 @@ int pyramid_init_attributes() {
     rc |= set_lds_attr<8>();
     rc |= set_lds_attr<10>();
     rc |= set_lds_attr<13>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_base<5>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TileGeom<5>::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_base_march<5>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)MarchGeom<5>::LDS_BYTES);
     if (e != hipSuccess) rc = -1;
     return rc;
 }
@@ -367,9 +292,11 @@ void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframe
                  int ntaps) {
     (void)ntaps;  // sigma 1.2489996 -> 11 taps
     const int w = 2 * W, h = 2 * H;
-    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, nframes);
-    hipLaunchKernelGGL(k_base<5>, grid, dim3(NTHREADS), TileGeom<5>::LDS_BYTES, st, frames, W, H, p.gauss[0],
-                       (size_t)IMAGES * w * h, taps);
+    dim3 grid;
+    int strip_h;
+    strip_grid(w, h, nframes, grid, strip_h);
+    hipLaunchKernelGGL(k_base_march<5>, grid, dim3(NTHREADS), MarchGeom<5>::LDS_BYTES, st, frames, W, H, p.gauss[0],
+                       (size_t)IMAGES * w * h, strip_h, taps);
 }
 
 void launch_blur_dog(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps) {
