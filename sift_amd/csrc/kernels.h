@@ -20,7 +20,8 @@ void launch_gradients(hipStream_t st, const Pyramid &p, int oct, int nframes);
 void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
                     FrameCounters *counters);
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
-                            DevKeypoint *oriented, int kp_cap, FrameCounters *counters, int32_t *cursors);
+                            DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
+                            int32_t *n_localized, int32_t *cursors);
 
 // kernels_keypoints.hip
 void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevKeypoint *sorted, DevKeypoint *final_kp,

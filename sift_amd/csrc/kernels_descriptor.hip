@@ -1,7 +1,7 @@
 // 4x4x8 descriptors: get_descriptors_parallel::operator() (sift.cpp:464-584).
 //
-// One 128-thread workgroup (two waves) per keypoint; workgroups pull keypoints from a
-// per-frame cursor.  Each wave takes every second row of the
+// One 256-thread workgroup per keypoint; workgroups pull keypoints from a
+// per-frame cursor.  Each wave takes every fourth row of the
 // (2*half_width+1)^2 window.  For a row, the columns that can pass the
 // rotated-window test of sift.cpp:503 form an interval (two strips |a*j+b| < L
 // intersected); the wave sweeps only that interval, widened by one pixel, with
@@ -15,7 +15,7 @@
 // The eight trilinear contributions of a sample are scattered with LDS double
 // atomics.  Only the inner 4x4x8 bins are kept (the border ring of the 6x6x8
 // tensor is discarded by sift.cpp:557-563, so contributions to it are never
-// issued), and there is one 128-bin copy per (wave, lane & 15) so that
+// issued), and there is one 128-bin copy per (wave, lane & 7) so that
 // neighbouring pixels, which mostly share a bin, rarely collide.  The 32
 // copies are summed in fixed order, then normalised, clipped at 0.2*norm,
 // scaled by 512 and rounded exactly as sift.cpp:564-573 does.  Output is one
@@ -29,8 +29,8 @@ namespace {
 
 constexpr int DBINS = 8;
 constexpr int INNER = WINDOW_WIDTH * WINDOW_WIDTH * DBINS;  // 128
-constexpr int NWAVES = 2;
-constexpr int COPIES_PER_WAVE = 16;
+constexpr int NWAVES = 4;
+constexpr int COPIES_PER_WAVE = 8;
 constexpr int NT = NWAVES * 64;  // threads per workgroup
 constexpr int ROWS_IN_FLIGHT = 4;
 constexpr int NCOPY = NWAVES * COPIES_PER_WAVE;

@@ -255,38 +255,75 @@ __device__ int localize(const Pyramid &p, int f, int oct, int img, int i, int j,
     return img;
 }
 
-__device__ __forceinline__ double wave_sum_fixed(double v) {
-    // xor butterfly: every lane adds the same pairs in the same order
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-// One wave per candidate: localize_extrema then get_keypoint_orientations
-// (sift.cpp:393-448).  Waves pull candidates from a per-frame cursor.
-__global__ __launch_bounds__(64) void k_localize_orient(Pyramid p, const Candidate *__restrict__ cand, int cand_cap,
-                                                         DevKeypoint *__restrict__ oriented, int kp_cap,
-                                                         FrameCounters *__restrict__ counters,
-                                                         int32_t *__restrict__ cursors) {
-    __shared__ double hist[BINS * 64];  // hist[bin][lane]: each lane owns a column
-    __shared__ double hsum[BINS];
-    __shared__ double smooth[BINS];
+// localize_extrema (sift.cpp:312-387), one thread per candidate.  Survivors are
+// appended to a per-frame list as keypoints with angle -1; the layer the
+// localisation ended on (where the orientation is measured) rides in `pad`.
+__global__ __launch_bounds__(256) void k_localize(Pyramid p, const Candidate *__restrict__ cand, int cand_cap,
+                                                   DevKeypoint *__restrict__ localized, int kp_cap,
+                                                   FrameCounters *__restrict__ counters,
+                                                   int32_t *__restrict__ n_localized) {
     const int f = blockIdx.y;
-    const int lane = threadIdx.x;
     int n = counters[f].candidates;
     if (n > cand_cap) n = cand_cap;
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    DevKeypoint kpt;
+    int layer = -1;
+    int oct = 0;
+    if (idx < n) {
+        const Candidate cd = cand[(size_t)f * cand_cap + idx];
+        oct = cd.oct;
+        layer = localize(p, f, cd.oct, cd.img, cd.i, cd.j, kpt);
+    }
+    // layer 0 (singular system) runs the orientation of a default keypoint in
+    // the reference, which emits nothing (sift.cpp:333-335, :401-409)
+    const bool keep = layer > 0;
+    const int slot = wave_append(keep, &n_localized[f]);
+    if (slot >= 0) {
+        if (slot < kp_cap) {
+            kpt.pad = layer | (oct << 8);
+            localized[(size_t)f * kp_cap + slot] = kpt;
+        } else {
+            counters[f].overflow = 1;
+        }
+    }
+}
+
+// get_keypoint_orientations (sift.cpp:393-448), one wave per localised
+// keypoint; waves pull keypoints from a per-frame cursor.
+//
+// The 36-bin histogram is kept as 16 partial histograms in LDS, one per
+// lane & 15; the four lanes that share a partial histogram add to it in four
+// separate passes (lanes 0-15, 16-31, ...), so no two lanes ever update the
+// same word at once and the summation order is fixed: results are
+// deterministic.  The Gaussian weight exp(wf*(i^2+j^2)) is the product of two
+// entries of a per-keypoint table exp(wf*t^2).
+constexpr int OCOPIES = 16;
+constexpr int OSTRIDE = OCOPIES + 1;  // bins start one LDS bank pair apart
+constexpr int OWAVES = 4;             // waves (= keypoints in flight) per workgroup
+constexpr int WTAB = 128;
+
+__global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeypoint *__restrict__ localized,
+                                                         int kp_cap, DevKeypoint *__restrict__ oriented,
+                                                         FrameCounters *__restrict__ counters,
+                                                         const int32_t *__restrict__ n_localized,
+                                                         int32_t *__restrict__ cursors) {
+    __shared__ double s_hist[OWAVES][BINS * OSTRIDE];
+    __shared__ double s_hsum[OWAVES][BINS];
+    __shared__ double s_smooth[OWAVES][BINS];
+    __shared__ double s_wtab[OWAVES][WTAB];
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *hist = s_hist[wv], *hsum = s_hsum[wv], *smooth = s_smooth[wv], *wtab = s_wtab[wv];
+    int n = n_localized[f];
+    if (n > kp_cap) n = kp_cap;
     for (;;) {
         int idx = 0;
         if (lane == 0) idx = atomicAdd(&cursors[f], 1);
         idx = __shfl(idx, 0);
         if (idx >= n) break;
-        const Candidate cd = cand[(size_t)f * cand_cap + idx];
-        DevKeypoint kpt;
-        const int layer = localize(p, f, cd.oct, cd.img, cd.i, cd.j, kpt);
-        // layer 0 (singular system) runs the orientation of a default keypoint
-        // in the reference, which emits nothing (sift.cpp:333-335, :401-409)
-        if (layer <= 0) continue;
-        const int oct = cd.oct;
+        const DevKeypoint kpt = localized[(size_t)f * kp_cap + idx];
+        const int layer = kpt.pad & 255, oct = kpt.pad >> 8;
         const int w = p.w[oct], h = p.h[oct];
         const Grad *L = p.grad[oct] + grad_off(p, oct, f, layer);
         const int base_x = (int)round(kpt.x / double(1 << oct));  // sift.cpp:398
@@ -294,36 +331,71 @@ __global__ __launch_bounds__(64) void k_localize_orient(Pyramid p, const Candida
         const double scale = SCALE_FACTOR * kpt.size / double(1 << (oct + 1));  // sift.cpp:401
         const int radius = (int)round(scale * RADIUS_FACTOR);
         const double weight_factor = -0.5 / (scale * scale);
-#pragma unroll
-        for (int b = 0; b < BINS; b++) hist[b * 64 + lane] = 0.0;
+        for (int t = lane; t < BINS * OSTRIDE; t += 64) hist[t] = 0.0;
+        const bool use_tab = radius < WTAB;
+        if (use_tab)
+            for (int t = lane; t <= radius; t += 64) wtab[t] = exp(weight_factor * (double)(t * t));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int n1 = 2 * radius + 1;
         const int total = n1 * n1;
         const float inv_n1 = 1.0f / (float)n1;
-        for (int s = lane; s < total; s += 64) {
-            int qi = (int)((float)s * inv_n1);
-            int rj = s - qi * n1;
-            if (rj < 0) { qi--; rj += n1; }
-            if (rj >= n1) { qi++; rj -= n1; }
-            const int i = qi - radius, j = rj - radius;
-            const int y = base_y + i, x = base_x + j;
-            if (y > 0 && y < h - 1 && x > 0 && x < w - 1) {  // sift.cpp:407,409
-                const Grad g = L[(size_t)y * w + x];           // mag, direction (sift.cpp:410-415)
-                const int index = ((int)round((g.ori * BINS) / 360) % BINS + BINS) % BINS;  // sift.cpp:416
-                hist[index * 64 + lane] += exp(weight_factor * (i * i + j * j)) * g.mag;
+        const int copy = lane & (OCOPIES - 1), pass_of_lane = lane >> 4;
+        // four samples per lane per trip, loads first
+        for (int s0 = lane; s0 < total; s0 += 64 * 4) {
+            Grad g[4];
+            int ii[4], jj[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = s0 + 64 * u;
+                int qi = (int)((float)s * inv_n1);
+                int rj = s - qi * n1;
+                if (rj < 0) { qi--; rj += n1; }
+                if (rj >= n1) { qi++; rj -= n1; }
+                ii[u] = qi - radius;
+                jj[u] = rj - radius;
+                const int y = base_y + ii[u], x = base_x + jj[u];
+                ok[u] = s < total && y > 0 && y < h - 1 && x > 0 && x < w - 1;  // sift.cpp:407,409
+                g[u].mag = 0.0;
+                g[u].ori = 0.0;
+                if (ok[u]) g[u] = L[(size_t)y * w + x];  // mag, direction (sift.cpp:410-415)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int index = ((int)round((g[u].ori * BINS) / 360) % BINS + BINS) % BINS;  // sift.cpp:416
+                double wgt = 0.0;
+                if (ok[u])
+                    wgt = use_tab ? wtab[abs(ii[u])] * wtab[abs(jj[u])]
+                                  : exp(weight_factor * (ii[u] * ii[u] + jj[u] * jj[u]));
+                const double add = wgt * g[u].mag;  // sift.cpp:417
+#pragma unroll
+                for (int pass = 0; pass < 4; pass++) {
+                    if (pass_of_lane == pass && ok[u]) hist[index * OSTRIDE + copy] += add;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
             }
         }
-        __syncthreads();
-        for (int b = 0; b < BINS; b++) {
-            const double t = wave_sum_fixed(hist[b * 64 + lane]);
-            if (lane == b) hsum[b] = t;
+        if (lane < BINS) {
+            double t = hist[lane * OSTRIDE];
+#pragma unroll
+            for (int c = 1; c < OCOPIES; c++) t += hist[lane * OSTRIDE + c];
+            hsum[lane] = t;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (lane < BINS) {
             const int i = lane;
             smooth[i] = (6 * hsum[i] + 4 * (hsum[(i + BINS - 1) % BINS] + hsum[(i + 1) % BINS]) +
                          hsum[(i + BINS - 2) % BINS] + hsum[(i + 2) % BINS]) / 16.;  // sift.cpp:426-429
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         double max_orientation = smooth[0];
         for (int b = 1; b < BINS; b++) max_orientation = fmax(max_orientation, smooth[b]);
         bool is_peak = false;
@@ -344,12 +416,15 @@ __global__ __launch_bounds__(64) void k_localize_orient(Pyramid p, const Candida
             if (slot < kp_cap) {
                 DevKeypoint nk = kpt;
                 nk.angle = (float)orientation;
+                nk.pad = 0;
                 oriented[(size_t)f * kp_cap + slot] = nk;
             } else {
                 counters[f].overflow = 1;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 
@@ -364,10 +439,12 @@ void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Cand
 }
 
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
-                            DevKeypoint *oriented, int kp_cap, FrameCounters *counters, int32_t *cursors) {
-    dim3 grid(512, nframes);
-    hipLaunchKernelGGL(k_localize_orient, grid, dim3(64), 0, st, p, cand, cand_cap, oriented, kp_cap, counters,
-                       cursors);
+                            DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
+                            int32_t *n_localized, int32_t *cursors) {
+    hipLaunchKernelGGL(k_localize, dim3((cand_cap + 255) / 256, nframes), dim3(256), 0, st, p, cand, cand_cap,
+                       localized, kp_cap, counters, n_localized);
+    hipLaunchKernelGGL(k_orient, dim3(1024 / OWAVES, nframes), dim3(64 * OWAVES), 0, st, p, localized, kp_cap,
+                       oriented, counters, n_localized, cursors);
 }
 
 }  // namespace sa

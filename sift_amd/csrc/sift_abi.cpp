@@ -90,7 +90,7 @@ struct sift_batch {
     int kp_cap = 0;
     uint8_t *d_desc = nullptr;
     FrameCounters *d_counters = nullptr;
-    int32_t *d_cursors = nullptr;  // [2][max_frames]: localize cursor, descriptor cursor
+    int32_t *d_cursors = nullptr;  // [3][max_frames]: orientation cursor, descriptor cursor, localised count
     Taps base_taps{};
     int base_ntaps = 0;
     Taps lvl_taps[IMAGES]{};
@@ -269,7 +269,7 @@ int sift_batch_create(sift_ctx *ctx, int w, int h, int max_frames, int max_keypo
     if ((e = hipMalloc((void **)&b->d_flags, F * cap * 2)) != hipSuccess) return cleanup(e, "hipMalloc(flags)");
     if ((e = hipMalloc((void **)&b->d_desc, F * cap * 128)) != hipSuccess) return cleanup(e, "hipMalloc(desc)");
     if ((e = hipMalloc((void **)&b->d_counters, F * sizeof(FrameCounters))) != hipSuccess) return cleanup(e, "hipMalloc(counters)");
-    if ((e = hipMalloc((void **)&b->d_cursors, 2 * F * sizeof(int32_t))) != hipSuccess) return cleanup(e, "hipMalloc(cursors)");
+    if ((e = hipMalloc((void **)&b->d_cursors, 3 * F * sizeof(int32_t))) != hipSuccess) return cleanup(e, "hipMalloc(cursors)");
     if ((e = hipMemset(b->d_counters, 0, F * sizeof(FrameCounters))) != hipSuccess) return cleanup(e, "hipMemset");
     *out = b;
     return SIFT_OK;
@@ -347,7 +347,7 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
     HIP_TRY(hipSetDevice(ctx->device));
     StageTimer tm{b, times != nullptr, 0, {}, st};
     HIP_TRY(hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(FrameCounters), st));
-    HIP_TRY(hipMemsetAsync(b->d_cursors, 0, 2 * (size_t)b->max_frames * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(b->d_cursors, 0, 3 * (size_t)b->max_frames * sizeof(int32_t), st));
 #define TIMED(stage, call)                                              \
     do {                                                                \
         if (tm.begin(stage)) return fail(SIFT_ERR_HIP, "hipEventRecord"); \
@@ -363,8 +363,9 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
         if (b->pyr.grad[o]) TIMED(SIFT_STAGE_GRADIENT, launch_gradients(st, b->pyr, o, n));
     for (int o = 0; o < b->pyr.octaves; o++)
         TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
-    TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_oriented, b->kp_cap,
-                                                      b->d_counters, b->d_cursors));
+    TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_sorted, b->d_oriented,
+                                                      b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames,
+                                                      b->d_cursors));
     TIMED(SIFT_STAGE_CLEAN,
           launch_clean(st, n, b->d_oriented, b->d_sorted, b->d_final, b->d_flags, b->kp_cap, b->d_counters));
     TIMED(SIFT_STAGE_DESCRIPTOR, launch_descriptors(st, b->pyr, n, b->d_final, b->kp_cap, b->d_counters,
