@@ -1,0 +1,80 @@
+// Drop-in for the reference's src/sift.hpp (kannavkm/SIFT, sift.hpp:20-118):
+// the same class, constructor, methods and public data members, with the work
+// done on an MI355X through the C ABI of include/sift_amd.h.
+//
+//   sift::sift_handler s(name, std::move(bgr_or_gray_mat));   // sift.hpp:23
+//   s.exec();                                                 // sift.hpp:25
+//   cv::Mat descriptors = s.get();                            // sift.hpp:27, N x 128 CV_32FC1
+//   s.keypoints;                                              // sift.hpp:93
+//
+// Differences from the reference, all outside the numeric results:
+//   * `base` (sift.hpp:90) is filled by exec(), not by the constructor;
+//   * get() on zero keypoints returns an empty 0 x 128 matrix instead of
+//     indexing descriptors[0] (sift.cpp:105);
+//   * "<name>_keypoints.png" (sift.cpp:89-90) is written only when the real
+//     OpenCV is available; "<name>.csv" (sift.cpp:114-121) and the stderr lines
+//     (sift.cpp:37-38, 69, 93, 96 and the TIMEIT lines) are always produced;
+//   * errors of the GPU library surface as std::runtime_error.
+#ifndef SIFT_H
+#define SIFT_H
+
+#if __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+#include <opencv2/features2d.hpp>
+#define SIFT_AMD_HAVE_OPENCV 1
+#else
+#include "cv_compat.hpp"
+#define SIFT_AMD_HAVE_OPENCV 0
+#endif
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace sift {
+
+class sift_handler {
+   public:
+    explicit sift_handler(std::string _name, cv::Mat &&_base);
+
+    void exec();
+
+    [[nodiscard]] cv::Mat get() const;
+
+    ~sift_handler();
+
+    sift_handler(const sift_handler &) = delete;
+    sift_handler &operator=(const sift_handler &) = delete;
+
+   public:
+    cv::Mat base, onex;
+    int32_t octaves;
+    std::string name;
+    std::vector<cv::KeyPoint> keypoints;
+    std::vector<std::vector<double>> descriptors;
+
+   private:
+    void dump_keypoints();
+
+    std::vector<unsigned char> gray_;  // 8-bit gray input, row-major
+    int width_ = 0, height_ = 0;
+};
+
+// Matcher used in place of cv::FlannBasedMatcher (main.cpp:48-51, 75): exact
+// top-2 nearest neighbours on the GPU.  query/train are N x 128 CV_32FC1
+// matrices as returned by sift_handler::get().
+struct match_result {
+    int queryIdx = -1;
+    int trainIdx = -1;   // nearest train descriptor
+    float distance = 0;  // L2 distance to it (DMatch::distance)
+    int trainIdx2 = -1;  // second nearest
+    float distance2 = 0;
+    bool ratio_ok = false;  // distance < 0.7f * distance2 (main.cpp:190-194)
+};
+std::vector<match_result> knn_match(const cv::Mat &query, const cv::Mat &train);
+// main.cpp:77-91: min_dist starts at 100; good <=> distance < 3 * min_dist.
+std::vector<match_result> good_matches(const std::vector<match_result> &matches);
+
+}  // namespace sift
+
+#endif
