@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pool", type=int, default=4, help="distinct batches resident in HBM, cycled over steps")
-    ap.add_argument("--knn-queries", type=int, default=65536)
+    ap.add_argument("--knn-queries", type=int, default=262144)
     ap.add_argument("--knn-train", type=int, default=1 << 20)
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")

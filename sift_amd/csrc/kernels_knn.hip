@@ -32,7 +32,7 @@ using v4i = __attribute__((ext_vector_type(4))) int;
 using v16i = __attribute__((ext_vector_type(16))) int;
 
 constexpr int TT = 128;     // train rows per LDS tile
-constexpr int QB = 2;       // 32-query column blocks per wave
+constexpr int QB = 4;       // 32-query column blocks per wave
 constexpr int QPB = 4 * QB * 32;  // queries per 256-thread workgroup
 constexpr int C_OFF = 126;
 
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
     for (int tile = tile_begin; tile < tile_end; tile++) {
         const int buf = (tile - tile_begin) & 1;
         if (tile + 1 < tile_end) fetch(tile + 1);
-#pragma unroll
+#pragma unroll 1
         for (int rb = 0; rb < TT / 32; rb++) {
             v16i cinit;
 #pragma unroll
@@ -185,23 +185,40 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
                 const uint4 a = s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))];
                 af[ks] = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
             }
+            // all QB accumulation chains first, then the checks, so that no check
+            // waits on the matrix pipeline
+            v16i acc[QB];
 #pragma unroll
             for (int qb = 0; qb < QB; qb++) {
-                v16i acc = cinit;
+                acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[qb][0], cinit, 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++)
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bf[qb][ks], acc, 0, 0, 0);
-                const int m = min16(acc);
-                if (__any(m < b2[qb])) {
-                    const int idx0 = tile * TT + rb * 32 + 4 * h;
+                for (int ks = 1; ks < 4; ks++)
+                    acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bf[qb][ks], acc[qb], 0, 0, 0);
+            }
+            bool hit[QB];
+            bool any_hit = false;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int s = acc[r];
-                        const int idx = idx0 + (r & 3) + 8 * (r >> 2);
-                        if (s < b1[qb]) {
-                            b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = s; i1[qb] = idx;
-                        } else if (s < b2[qb]) {
-                            b2[qb] = s; i2[qb] = idx;
+            for (int qb = 0; qb < QB; qb++) {
+                hit[qb] = min16(acc[qb]) < b2[qb];
+                any_hit |= hit[qb];
+            }
+            if (__any(any_hit)) {
+                const int idx0 = tile * TT + rb * 32 + 4 * h;
+#pragma unroll
+                for (int qb = 0; qb < QB; qb++) {
+                    if (__any(hit[qb])) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int sv = acc[qb][r];
+                            // most rows lose against the running second-best in every lane: skip them whole
+                            if (__any(sv < b2[qb])) {
+                                const int idx = idx0 + (r & 3) + 8 * (r >> 2);
+                                if (sv < b1[qb]) {
+                                    b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = sv; i1[qb] = idx;
+                                } else if (sv < b2[qb]) {
+                                    b2[qb] = sv; i2[qb] = idx;
+                                }
+                            }
                         }
                     }
                 }
@@ -254,7 +271,7 @@ __global__ void k_knn2_merge(const sift_knn2 *__restrict__ parts, int nparts, in
 int choose_splits(int nq, int nt) {
     const int qblocks = (nq + QPB - 1) / QPB;
     const int ntiles = (nt + TT - 1) / TT;
-    int splits = (1024 + qblocks - 1) / qblocks;
+    int splits = (512 + qblocks - 1) / qblocks;  // at least two workgroups per CU
     if (splits > ntiles) splits = ntiles;
     if (splits < 1) splits = 1;
     return splits;
