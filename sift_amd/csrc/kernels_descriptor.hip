@@ -3,8 +3,8 @@
 // One 256-thread workgroup per keypoint; workgroups pull keypoints from a
 // per-frame cursor.  Each wave takes every fourth row of the
 // (2*half_width+1)^2 window.  For a row, the columns that can pass the
-// rotated-window test of sift.cpp:503 form an interval (two strips |a*j+b| < L
-// intersected); the wave sweeps only that interval, widened by one pixel, with
+// rotated-window test of sift.cpp:503 form an interval (two strips
+// -1 < s*j + B < 4 intersected); the wave sweeps only that interval, widened by one pixel, with
 // lanes on consecutive columns (coalesced reads), and every sample still takes
 // the exact test.  A sample's gradient magnitude and direction come from the
 // precomputed gradient plane of the keypoint's Gaussian level, and its
@@ -36,40 +36,39 @@ constexpr int ROWS_IN_FLIGHT = 4;
 constexpr int NCOPY = NWAVES * COPIES_PER_WAVE;
 constexpr int CSTRIDE = INNER + 1;  // copies start one LDS bank pair apart, so equal bins of different copies do not share a bank
 
-// Intersect [lo, hi] with { j : |a*j + b| < L }.
-__device__ __forceinline__ void clip_strip(double a, double b, double L, double &lo, double &hi) {
-    if (fabs(a) < 1e-12) {
-        if (!(fabs(b) < L)) hi = lo - 4;  // empty
+// Intersect [lo, hi] with { j : -1 < s*j + B < WINDOW_WIDTH }; `is` = 1/s.
+__device__ __forceinline__ void clip_strip(double s, double is, bool flat, double B, double &lo, double &hi) {
+    if (flat) {
+        if (!(B > -1 && B < WINDOW_WIDTH)) hi = lo - 4;  // empty
         return;
     }
-    double j1 = (-L - b) / a, j2 = (L - b) / a;
-    if (j1 > j2) {
-        const double t = j1;
-        j1 = j2;
-        j2 = t;
-    }
-    lo = fmax(lo, j1);
-    hi = fmin(hi, j2);
+    const double j1 = (-1 - B) * is, j2 = (WINDOW_WIDTH - B) * is;
+    lo = fmax(lo, fmin(j1, j2));
+    hi = fmin(hi, fmax(j1, j2));
 }
+
+struct DescShared {
+    double wtab[256];
+    double vals[INNER];
+    double red[INNER];
+    double tensor[NCOPY][CSTRIDE];
+    int idx;
+};
 
 __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
                                                       const FrameCounters *__restrict__ counters,
                                                       int32_t *__restrict__ cursors, uint8_t *__restrict__ desc) {
-    __shared__ double tensor[NCOPY][CSTRIDE];
-    __shared__ double vals[INNER];
-    __shared__ double red[INNER];
-    __shared__ double wtab[256];
-    __shared__ int s_idx;
+    __shared__ DescShared sm;
     const int f = blockIdx.y;
     const int tid = threadIdx.x;
     const int wv = tid >> 6, lane = tid & 63;
     int n = counters[f].keypoints;
     if (n > kp_cap) n = kp_cap;
     for (;;) {
-        if (tid == 0) s_idx = atomicAdd(&cursors[f], 1);
-        for (int t = tid; t < NCOPY * CSTRIDE; t += NT) (&tensor[0][0])[t] = 0.0;
+        if (tid == 0) sm.idx = atomicAdd(&cursors[f], 1);
+        for (int t = tid; t < NCOPY * CSTRIDE; t += NT) (&sm.tensor[0][0])[t] = 0.0;
         __syncthreads();
-        const int it = s_idx;
+        const int it = sm.idx;
         if (it >= n) break;
         const DevKeypoint kpt = kps[(size_t)f * kp_cap + it];
         int octave = kpt.octave & 255;           // sift.cpp:469
@@ -95,17 +94,23 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
         const double wscale = weight_multiplier * inv_hw * inv_hw;
         const bool use_tab = half_width < 256;
         if (use_tab)
-            for (int t = tid; t <= half_width; t += NT) wtab[t] = exp(wscale * (double)(t * t));
+            for (int t = tid; t <= half_width; t += NT) sm.wtab[t] = exp(wscale * (double)(t * t));
         __syncthreads();
-        double *T = tensor[wv * COPIES_PER_WAVE + (lane & (COPIES_PER_WAVE - 1))];
-        // bin in (-1, 4)  <=>  |rot / hist_width| < 2.5
-        const double L = 0.5 * (WINDOW_WIDTH + 1) * hist_width;
+        // bin_row = (sin*j + cos*i)/hist_width + 1.5 = su*j + Bu(i); bin_col = (sin*i - cos*j)/hist_width + 1.5
+        // = sv*j + Bv(i) (sift.cpp:497-501); a sample counts when both lie in (-1, 4) (sift.cpp:503).
+        const double su = sinv * inv_hw, sv = -cosv * inv_hw;
+        const bool flat_u = fabs(su) < 1e-12, flat_v = fabs(sv) < 1e-12;
+        const double isu = flat_u ? 0.0 : 1.0 / su, isv = flat_v ? 0.0 : 1.0 / sv;
+        const double half_bins = 0.5 * (WINDOW_WIDTH - 1);
+        const double ang_bins = angle * bins_per_degree;
+        double *T = sm.tensor[wv * COPIES_PER_WAVE + (lane & (COPIES_PER_WAVE - 1))];
         // image bounds on the column: 0 < pt_x + j < width - 1 (sift.cpp:506)
         const int jmin = max(-half_width, 1 - pt_x), jmax = min(half_width, width - 2 - pt_x);
         // Each wave takes rows wv, wv+4, ...; ROWS_IN_FLIGHT rows are handled together so
         // that their gradient loads are all issued before the first one is consumed.
         for (int i0 = -half_width + wv; i0 <= half_width; i0 += NWAVES * ROWS_IN_FLIGHT) {
             int jlo[ROWS_IN_FLIGHT], jhi[ROWS_IN_FLIGHT];
+            double Bu[ROWS_IN_FLIGHT], Bv[ROWS_IN_FLIGHT], wi[ROWS_IN_FLIGHT];
             int longest = 0;
 #pragma unroll
             for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
@@ -113,88 +118,104 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                 const int win_row = pt_y + i;
                 jlo[r] = 0;
                 jhi[r] = -1;
+                Bu[r] = (cosv * i) * inv_hw + half_bins;
+                Bv[r] = (sinv * i) * inv_hw + half_bins;
+                wi[r] = 0.0;
                 if (i <= half_width && win_row > 0 && win_row < height - 1) {  // sift.cpp:506 (rows)
                     double lo = jmin, hi = jmax;
-                    clip_strip(sinv, cosv * i, L, lo, hi);    // |sin*j + cos*i| < L
-                    clip_strip(-cosv, sinv * i, L, lo, hi);   // |sin*i - cos*j| < L
+                    clip_strip(su, isu, flat_u, Bu[r], lo, hi);
+                    clip_strip(sv, isv, flat_v, Bv[r], lo, hi);
                     if (hi >= lo - 2) {
                         jlo[r] = max(jmin, (int)floor(lo) - 1);
                         jhi[r] = min(jmax, (int)ceil(hi) + 1);
                     }
+                    wi[r] = use_tab ? sm.wtab[abs(i)] : exp(wscale * (double)(i * i));
                 }
                 longest = max(longest, jhi[r] - jlo[r] + 1);
             }
             for (int c = 0; c < longest; c += 64) {
+                // Everything the four rows read (gradients from memory, column weights from the
+                // LDS table) is requested here, before the first atomic of the group: an LDS read
+                // issued between atomics would have to wait for all of them.  The loads are
+                // unconditional, at addresses clamped into the plane, so that all four are in
+                // flight together; lanes outside their row's interval discard what they read.
                 Grad g[ROWS_IN_FLIGHT];
+                double wj[ROWS_IN_FLIGHT];
 #pragma unroll
                 for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
                     const int j = jlo[r] + c + lane;
-                    g[r].mag = 0.0;
-                    g[r].ori = 0.0;
-                    if (j <= jhi[r]) g[r] = image[(size_t)(pt_y + i0 + r * NWAVES) * width + pt_x + j];  // sift.cpp:507-510
+                    const int yy = min(max(pt_y + i0 + r * NWAVES, 0), height - 1);
+                    const int xx = min(max(pt_x + j, 0), width - 1);
+                    g[r] = image[(size_t)yy * width + xx];  // sift.cpp:507-510
+                    wj[r] = sm.wtab[min(abs(j), 255)];
                 }
 #pragma unroll
                 for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
-                    const int i = i0 + r * NWAVES;
                     const int j = jlo[r] + c + lane;
                     if (j > jhi[r]) continue;
-                    const double row_rotation = sinv * j + cosv * i;  // sift.cpp:497
-                    const double col_rotation = sinv * i - cosv * j;  // sift.cpp:498
-                    const double rr = row_rotation * inv_hw, cr = col_rotation * inv_hw;
-                    const double bin_row = rr + 0.5 * (WINDOW_WIDTH - 1);
-                    const double bin_col = cr + 0.5 * (WINDOW_WIDTH - 1);
+                    const double dj = (double)j;
+                    const double bin_row = su * dj + Bu[r];
+                    const double bin_col = sv * dj + Bv[r];
                     if (!(bin_row > -1 && bin_col > -1 && bin_row < WINDOW_WIDTH && bin_col < WINDOW_WIDTH)) continue;
-                    const double weight =
-                        use_tab ? wtab[abs(i)] * wtab[abs(j)] : exp(wscale * (double)(i * i + j * j));
-                    const double magnitude = g[r].mag * weight;                       // sift.cpp:512-518
-                    const double orientation = (g[r].ori - angle) * bins_per_degree;  // sift.cpp:519
-                    const int row_bin = (int)floor(bin_row);
-                    const int col_bin = (int)floor(bin_col);
-                    int orient_bin = (int)floor(orientation);
-                    const double row_bin_pr = bin_row - row_bin;
-                    const double col_bin_pr = bin_col - col_bin;
-                    const double orient_bin_pr = orientation - orient_bin;
-                    if (orient_bin < 0) orient_bin += DBINS;
-                    if (orient_bin >= DBINS) orient_bin -= DBINS;
-#pragma unroll
-                    for (int a = 0; a < 2; a++)
-#pragma unroll
-                        for (int b = 0; b < 2; b++) {
-                            // tensor cell (row_bin+1+a, col_bin+1+b) of the 6x6 grid; inner cells are 1..4
-                            const int ri = row_bin + a, cj = col_bin + b;
-                            if ((unsigned)ri < (unsigned)WINDOW_WIDTH && (unsigned)cj < (unsigned)WINDOW_WIDTH) {
-#pragma unroll
-                                for (int k = 0; k < 2; k++) {
-                                    double cc = magnitude;
-                                    cc *= (!a ? (1 - row_bin_pr) : (row_bin_pr));
-                                    cc *= (!b ? (1 - col_bin_pr) : (col_bin_pr));
-                                    cc *= (!k ? (1 - orient_bin_pr) : (orient_bin_pr));
-                                    const int ob = ((orient_bin + k) % DBINS + DBINS) % DBINS;
-                                    atomicAdd(&T[(ri * WINDOW_WIDTH + cj) * DBINS + ob], cc);
-                                }
-                            }
-                        }
+                    // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) (sift.cpp:512-517) as a product of two table entries
+                    const double wcol = use_tab ? wj[r] : exp(wscale * (double)(j * j));
+                    const double magnitude = g[r].mag * (wi[r] * wcol);                  // sift.cpp:518
+                    const double orientation = g[r].ori * bins_per_degree - ang_bins;  // sift.cpp:519
+                    const double fr = floor(bin_row), fc = floor(bin_col), fo = floor(orientation);
+                    const int row_bin = (int)fr, col_bin = (int)fc;
+                    const double row_pr = bin_row - fr, col_pr = bin_col - fc, ori_pr = orientation - fo;
+                    const int ob0 = (int)fo & (DBINS - 1), ob1 = ((int)fo + 1) & (DBINS - 1);
+                    // trilinear split (sift.cpp:527-551): each step peels the upper share off the lower one
+                    const double m1 = magnitude * row_pr, m0 = magnitude - m1;
+                    const double m01 = m0 * col_pr, m00 = m0 - m01;
+                    const double m11 = m1 * col_pr, m10 = m1 - m11;
+                    // cell (row_bin + a, col_bin + b) of the inner 4x4 grid; the border ring is dropped
+                    double *cell = T + (row_bin * WINDOW_WIDTH + col_bin) * DBINS;
+                    const bool r0 = (unsigned)row_bin < (unsigned)WINDOW_WIDTH;
+                    const bool r1 = (unsigned)(row_bin + 1) < (unsigned)WINDOW_WIDTH;
+                    const bool c0 = (unsigned)col_bin < (unsigned)WINDOW_WIDTH;
+                    const bool c1 = (unsigned)(col_bin + 1) < (unsigned)WINDOW_WIDTH;
+                    if (r0 && c0) {
+                        const double hi = m00 * ori_pr;
+                        atomicAdd(cell + ob0, m00 - hi);
+                        atomicAdd(cell + ob1, hi);
+                    }
+                    if (r0 && c1) {
+                        const double hi = m01 * ori_pr;
+                        atomicAdd(cell + DBINS + ob0, m01 - hi);
+                        atomicAdd(cell + DBINS + ob1, hi);
+                    }
+                    if (r1 && c0) {
+                        const double hi = m10 * ori_pr;
+                        atomicAdd(cell + WINDOW_WIDTH * DBINS + ob0, m10 - hi);
+                        atomicAdd(cell + WINDOW_WIDTH * DBINS + ob1, hi);
+                    }
+                    if (r1 && c1) {
+                        const double hi = m11 * ori_pr;
+                        atomicAdd(cell + (WINDOW_WIDTH + 1) * DBINS + ob0, m11 - hi);
+                        atomicAdd(cell + (WINDOW_WIDTH + 1) * DBINS + ob1, hi);
+                    }
                 }
             }
         }
         __syncthreads();
         // inner 4x4x8 bins (sift.cpp:557-563), copies summed in fixed order
         if (tid < INNER) {
-            double v = tensor[0][tid];
+            double v = sm.tensor[0][tid];
 #pragma unroll 8
-            for (int c = 1; c < NCOPY; c++) v += tensor[c][tid];
-            vals[tid] = v;
-            red[tid] = v * v;
+            for (int c = 1; c < NCOPY; c++) v += sm.tensor[c][tid];
+            sm.vals[tid] = v;
+            sm.red[tid] = v * v;
         }
         __syncthreads();
         for (int sft = INNER / 2; sft > 0; sft >>= 1) {
-            if (tid < sft) red[tid] += red[tid + sft];
+            if (tid < sft) sm.red[tid] += sm.red[tid + sft];
             __syncthreads();
         }
         if (tid < INNER) {
-            const double norm = sqrt(red[0]);            // sift.cpp:564-565
+            const double norm = sqrt(sm.red[0]);          // sift.cpp:564-565
             const double thresh = norm * DESCRIPTOR_MAX;  // sift.cpp:566
-            double I = vals[tid];
+            double I = sm.vals[tid];
             I = I > thresh ? thresh : I;
             I /= fmax(norm, EPS);
             I = round(I * 512);

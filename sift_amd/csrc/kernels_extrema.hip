@@ -39,8 +39,9 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
                                                   FrameCounters *__restrict__ counters) {
     __shared__ double s[NDOG][EX_TH + 2][EX_TW + 2];
     const int w = p.w[oct], h = p.h[oct];
-    const int f = blockIdx.z;
-    const int x0 = BORDER + blockIdx.x * EX_TW, y0 = BORDER + blockIdx.y * EX_TH;
+    const TileId tile = xcd_tile_id();
+    const int f = tile.z;
+    const int x0 = BORDER + tile.x * EX_TW, y0 = BORDER + tile.y * EX_TH;
     const size_t plane = (size_t)w * h;
     const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
     const int x = threadIdx.x & 63, ty = threadIdx.x >> 6;

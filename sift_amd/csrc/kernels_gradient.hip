@@ -45,26 +45,51 @@ __device__ __forceinline__ double direction_degrees(double dy, double dx) {
     return orientation;
 }
 
-// grid: (ceil(w/64), ceil(h/4), frames*SCALES)
+// grid: (ceil(w/64), ceil(h/32), frames*SCALES), renumbered per XCD.  A wave
+// owns 64 columns x 8 rows: it loads the ten centre-column rows and the left and
+// right neighbours of its eight rows into registers first (every load in
+// flight together), then evaluates the eight pixels.
+constexpr int GR_ROWS = 8;             // rows per wave
+constexpr int GR_TH = 4 * GR_ROWS;     // rows per workgroup
+
 __global__ __launch_bounds__(256) void k_gradients(const double *__restrict__ gauss, Grad *__restrict__ grad, int w,
                                                     int h) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const int frame = blockIdx.z / SCALES, layer = blockIdx.z % SCALES + 1;
+    const TileId tile = xcd_tile_id();
+    const int x = tile.x * 64 + (threadIdx.x & 63);
+    const int y0 = tile.y * GR_TH + (threadIdx.x >> 6) * GR_ROWS;
+    if (y0 >= h) return;
+    const int frame = tile.z / SCALES, layer = tile.z % SCALES + 1;
     const size_t plane = (size_t)w * h;
     const double *L = gauss + ((size_t)frame * IMAGES + layer) * plane;
     Grad *G = grad + ((size_t)frame * SCALES + (layer - 1)) * plane;
-    Grad g = {0.0, 0.0};
-    // windows only sample 0 < x < w-1, 0 < y < h-1 (sift.cpp:407-409, :506)
-    if (x > 0 && x < w - 1 && y > 0 && y < h - 1) {
-        const double *q = L + (size_t)y * w + x;
-        const double dx = q[1] - q[-1];
-        const double dy = q[-w] - q[w];
-        g.mag = sqrt(dx * dx + dy * dy);
-        g.ori = direction_degrees(dy, dx);
+    const int xc = min(x, w - 1), xl = max(xc - 1, 0), xr = min(xc + 1, w - 1);
+    double c[GR_ROWS + 2], l[GR_ROWS], r[GR_ROWS];
+#pragma unroll
+    for (int k = 0; k < GR_ROWS + 2; k++) {
+        const int yy = min(max(y0 - 1 + k, 0), h - 1);
+        c[k] = L[(size_t)yy * w + xc];
     }
-    G[(size_t)y * w + x] = g;
+#pragma unroll
+    for (int k = 0; k < GR_ROWS; k++) {
+        const int yy = min(y0 + k, h - 1);
+        l[k] = L[(size_t)yy * w + xl];
+        r[k] = L[(size_t)yy * w + xr];
+    }
+    if (x >= w) return;
+#pragma unroll
+    for (int k = 0; k < GR_ROWS; k++) {
+        const int y = y0 + k;
+        if (y >= h) break;
+        Grad g = {0.0, 0.0};
+        // windows only sample 0 < x < w-1, 0 < y < h-1 (sift.cpp:407-409, :506)
+        if (x > 0 && x < w - 1 && y > 0 && y < h - 1) {
+            const double dx = r[k] - l[k];
+            const double dy = c[k] - c[k + 2];
+            g.mag = sqrt(dx * dx + dy * dy);
+            g.ori = direction_degrees(dy, dx);
+        }
+        G[(size_t)y * w + x] = g;
+    }
 }
 
 }  // namespace
@@ -72,7 +97,7 @@ __global__ __launch_bounds__(256) void k_gradients(const double *__restrict__ ga
 void launch_gradients(hipStream_t st, const Pyramid &p, int oct, int nframes) {
     if (!p.grad[oct]) return;
     const int w = p.w[oct], h = p.h[oct];
-    dim3 grid((w + 63) / 64, (h + 3) / 4, nframes * SCALES);
+    dim3 grid((w + 63) / 64, (h + GR_TH - 1) / GR_TH, nframes * SCALES);
     hipLaunchKernelGGL(k_gradients, grid, dim3(256), 0, st, p.gauss[oct], p.grad[oct], w, h);
 }
 

@@ -80,13 +80,13 @@ struct UpsampleSource {
 template <int R, class Source>
 __device__ __forceinline__ void march(const Source source, double *__restrict__ out, double *__restrict__ dog,
                                       double *__restrict__ nxt, int w, int h, int nw, int nh, int strip_h,
-                                      const Taps &taps, double *smem) {
+                                      const Taps &taps, double *smem, const TileId tile) {
     using G = MarchGeom<R>;
     static_assert(R < MCH, "the centre rows of one step lie in the last two staging buffers");
     double *ring = smem + 2 * MCH * G::PIN;
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * TW;
-    const int ys = blockIdx.y * strip_h;
+    const int tx0 = tile.x * TW;
+    const int ys = tile.y * strip_h;
     const int ye = min(h, ys + strip_h);
     const int nsteps = (ye - ys + 2 * R + MCH - 1) / MCH;
 
@@ -193,10 +193,11 @@ __global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restric
                                                           size_t dog_frame_stride, size_t next_frame_stride,
                                                           int strip_h, Taps taps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const size_t f = blockIdx.z;
+    const TileId tile = xcd_tile_id();
+    const size_t f = tile.z;
     const LevelSource source{in + f * in_frame_stride, w};
     march<R>(source, out + f * in_frame_stride, dog + f * dog_frame_stride,
-             next ? next + f * next_frame_stride : nullptr, w, h, nw, nh, strip_h, taps, smem);
+             next ? next + f * next_frame_stride : nullptr, w, h, nw, nh, strip_h, taps, smem, tile);
 }
 
 // gray u8 -> double -> 2x bilinear upsample -> base blur (sift.cpp:30, :40-42).
@@ -205,9 +206,10 @@ __global__ __launch_bounds__(NTHREADS) void k_base_march(const uint8_t *__restri
                                                           double *__restrict__ out, size_t out_frame_stride,
                                                           int strip_h, Taps taps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const size_t f = blockIdx.z;
+    const TileId tile = xcd_tile_id();
+    const size_t f = tile.z;
     const UpsampleSource source{frames + f * (size_t)W * H, W, H};
-    march<R>(source, out + f * out_frame_stride, nullptr, nullptr, 2 * W, 2 * H, 0, 0, strip_h, taps, smem);
+    march<R>(source, out + f * out_frame_stride, nullptr, nullptr, 2 * W, 2 * H, 0, 0, strip_h, taps, smem, tile);
 }
 
 // strips of 64 columns, cut vertically so that the launch has >= ~2048 workgroups
