@@ -294,11 +294,11 @@ __global__ __launch_bounds__(256) void k_localize(Pyramid p, const Candidate *__
 // keypoint; waves pull keypoints from a per-frame cursor.
 //
 // The 36-bin histogram is kept as 16 partial histograms in LDS, one per
-// lane & 15; the four lanes that share a partial histogram add to it in four
-// separate passes (lanes 0-15, 16-31, ...), so no two lanes ever update the
-// same word at once and the summation order is fixed: results are
-// deterministic.  The Gaussian weight exp(wf*(i^2+j^2)) is the product of two
-// entries of a per-keypoint table exp(wf*t^2).
+// lane & 15, updated with LDS double atomics; a partial histogram is only ever
+// touched by the four lanes of one wave that share it, in program order, so
+// the summation order is fixed and results are reproducible.  The Gaussian
+// weight exp(wf*(i^2+j^2)) is the product of two entries of a per-keypoint
+// table exp(wf*t^2).
 constexpr int OCOPIES = 16;
 constexpr int OSTRIDE = OCOPIES + 1;  // bins start one LDS bank pair apart
 constexpr int OWAVES = 4;             // waves (= keypoints in flight) per workgroup
@@ -342,11 +342,13 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
         const int n1 = 2 * radius + 1;
         const int total = n1 * n1;
         const float inv_n1 = 1.0f / (float)n1;
-        const int copy = lane & (OCOPIES - 1), pass_of_lane = lane >> 4;
-        // four samples per lane per trip, loads first
+        const int copy = lane & (OCOPIES - 1);
+        // Four samples per lane per trip.  Gradient loads are unconditional (addresses clamped
+        // into the plane) and the weight-table reads come before the first atomic, so all of a
+        // trip's reads are in flight together; samples outside the image are discarded.
         for (int s0 = lane; s0 < total; s0 += 64 * 4) {
             Grad g[4];
-            int ii[4], jj[4];
+            double wgt[4];
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -355,31 +357,24 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
                 int rj = s - qi * n1;
                 if (rj < 0) { qi--; rj += n1; }
                 if (rj >= n1) { qi++; rj -= n1; }
-                ii[u] = qi - radius;
-                jj[u] = rj - radius;
-                const int y = base_y + ii[u], x = base_x + jj[u];
+                const int ii = qi - radius, jj = rj - radius;
+                const int y = base_y + ii, x = base_x + jj;
                 ok[u] = s < total && y > 0 && y < h - 1 && x > 0 && x < w - 1;  // sift.cpp:407,409
-                g[u].mag = 0.0;
-                g[u].ori = 0.0;
-                if (ok[u]) g[u] = L[(size_t)y * w + x];  // mag, direction (sift.cpp:410-415)
+                const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+                g[u] = L[(size_t)yc * w + xc];  // mag, direction (sift.cpp:410-415)
+                wgt[u] = use_tab ? wtab[min(abs(ii), WTAB - 1)] * wtab[min(abs(jj), WTAB - 1)]
+                                 : exp(weight_factor * (ii * ii + jj * jj));
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                if (!ok[u]) continue;
                 const int index = ((int)round((g[u].ori * BINS) / 360) % BINS + BINS) % BINS;  // sift.cpp:416
-                double wgt = 0.0;
-                if (ok[u])
-                    wgt = use_tab ? wtab[abs(ii[u])] * wtab[abs(jj[u])]
-                                  : exp(weight_factor * (ii[u] * ii[u] + jj[u] * jj[u]));
-                const double add = wgt * g[u].mag;  // sift.cpp:417
-#pragma unroll
-                for (int pass = 0; pass < 4; pass++) {
-                    if (pass_of_lane == pass && ok[u]) hist[index * OSTRIDE + copy] += add;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
+                atomicAdd(&hist[index * OSTRIDE + copy], wgt[u] * g[u].mag);                  // sift.cpp:417
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (lane < BINS) {
             double t = hist[lane * OSTRIDE];
 #pragma unroll

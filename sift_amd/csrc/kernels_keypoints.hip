@@ -49,33 +49,63 @@ __device__ __forceinline__ int cmp_key(const SortKey &a, const SortKey &b) {
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_rank_sort(const DevKeypoint *__restrict__ in, DevKeypoint *__restrict__ out,
-                                                    int kp_cap, const FrameCounters *__restrict__ counters) {
-    __shared__ SortKey tile[256];
+// Rank of a keypoint = number of keypoints that sort before it.  Candidates
+// are first compared on the x key alone, four broadcast LDS words at a time;
+// a candidate with the same x (another orientation of the same extremum,
+// mostly) is noted in a bit mask, and only those take the full six-word
+// comparison afterwards.
+constexpr int RS_T = 128;  // threads per workgroup = keys per LDS tile
+
+__global__ __launch_bounds__(RS_T) void k_rank_sort(const DevKeypoint *__restrict__ in, DevKeypoint *__restrict__ out,
+                                                     int kp_cap, const FrameCounters *__restrict__ counters) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile_x[RS_T];
+    __shared__ SortKey tile[RS_T];
     const int f = blockIdx.y;
     int n = counters[f].oriented;
     if (n > kp_cap) n = kp_cap;
-    const int i0 = blockIdx.x * 256;
+    const int i0 = blockIdx.x * RS_T;
     if (i0 >= n) return;
     in += (size_t)f * kp_cap;
     out += (size_t)f * kp_cap;
     const int i = i0 + threadIdx.x;
     DevKeypoint me;
-    SortKey mk;
+    SortKey mk, nk;
+    for (int q = 0; q < 6; q++) mk.k[q] = nk.k[q] = 0xffffffffu;  // past-the-end keys sort last
     if (i < n) {
         me = in[i];
         mk = make_key(me);
     }
+    const uint32_t mx = mk.k[0];
     int rank = 0;
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        const int j = j0 + threadIdx.x;
-        if (j < n) tile[threadIdx.x] = make_key(in[j]);
+    if ((int)threadIdx.x < n) nk = make_key(in[threadIdx.x]);
+    for (int j0 = 0; j0 < n; j0 += RS_T) {
+        tile[threadIdx.x] = nk;
+        tile_x[threadIdx.x] = nk.k[0];
         __syncthreads();
-        const int m = min(256, n - j0);
-        if (i < n) {
-            for (int t = 0; t < m; t++) {
+        // next tile's key, loaded while this one is scanned
+        const int jn = j0 + RS_T + threadIdx.x;
+        for (int q = 0; q < 6; q++) nk.k[q] = 0xffffffffu;
+        if (jn < n) nk = make_key(in[jn]);
+        uint32_t eq[RS_T / 32];
+#pragma unroll
+        for (int w = 0; w < RS_T / 32; w++) eq[w] = 0;
+#pragma unroll
+        for (int t4 = 0; t4 < RS_T / 4; t4++) {
+            const uint4 tx = reinterpret_cast<const uint4 *>(tile_x)[t4];
+            rank += (tx.x < mx) + (tx.y < mx) + (tx.z < mx) + (tx.w < mx);
+            const uint32_t bits = (tx.x == mx ? 1u : 0u) | (tx.y == mx ? 2u : 0u) | (tx.z == mx ? 4u : 0u) |
+                                  (tx.w == mx ? 8u : 0u);
+            eq[t4 >> 3] |= bits << ((t4 & 7) * 4);
+        }
+#pragma unroll
+        for (int w = 0; w < RS_T / 32; w++) {
+            uint32_t m = eq[w];
+            while (m) {
+                const int t = w * 32 + __builtin_ctz(m);
+                m &= m - 1;
+                const int j = j0 + t;
                 const int c = cmp_key(tile[t], mk);
-                rank += (c < 0) || (c == 0 && (j0 + t) < i);
+                rank += j < n && ((c < 0) || (c == 0 && j < i));
             }
         }
         __syncthreads();
@@ -153,8 +183,8 @@ __global__ __launch_bounds__(1024) void k_unique_finalize(const DevKeypoint *__r
 
 void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevKeypoint *sorted, DevKeypoint *final_kp,
                   uint8_t *flags, int kp_cap, FrameCounters *counters) {
-    dim3 grid((kp_cap + 255) / 256, nframes);
-    hipLaunchKernelGGL(k_rank_sort, grid, dim3(256), 0, st, oriented, sorted, kp_cap, counters);
+    dim3 grid((kp_cap + RS_T - 1) / RS_T, nframes);
+    hipLaunchKernelGGL(k_rank_sort, grid, dim3(RS_T), 0, st, oriented, sorted, kp_cap, counters);
     hipLaunchKernelGGL(k_unique_finalize, dim3(nframes), dim3(1024), 0, st, sorted, final_kp, flags, kp_cap, counters);
 }
 
