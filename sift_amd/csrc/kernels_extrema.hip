@@ -32,7 +32,7 @@ __device__ __forceinline__ int wave_append(bool flag, int32_t *counter) {
 // is_pixel_extremum (sift.cpp:264-281) for the three scanned layers.  A
 // workgroup stages a 64x16 pixel tile (plus a one-pixel halo) of all five DoG
 // levels in LDS, so every DoG value is read from HBM once; each thread then
-// tests four pixels in three layers against their 26 neighbours out of LDS.
+// tests four consecutive pixels of a column in the three scanned layers.
 constexpr int EX_TW = 64, EX_TH = 16;
 
 __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
@@ -49,69 +49,76 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
         // All loads of the tile are issued before the first LDS write, with row and
         // column indices clamped into the image instead of branching: tested pixels
         // lie BORDER pixels inside, so a clamped halo value is never compared.
-        constexpr int NR = (EX_TH + 2 + 3) / 4;  // tile rows per thread
-        const int gx = min(x0 - 1 + x, w - 1);
-        const int gx2 = min(x0 - 1 + EX_TW + (x & 1), w - 1);
-        double v[NDOG][NR], v2[NDOG][NR];
+        constexpr int TILE = (EX_TH + 2) * (EX_TW + 2);
+        constexpr int NL = (TILE + 255) / 256;  // tile elements per thread and level
+        int goff[NL], soff[NL];
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int idx = min((int)threadIdx.x + 256 * u, TILE - 1);  // the last few threads repeat the last element
+            const int r = idx / (EX_TW + 2), c = idx - r * (EX_TW + 2);
+            goff[u] = min(y0 - 1 + r, h - 1) * w + min(x0 - 1 + c, w - 1);
+            soff[u] = idx;
+        }
+        double v[NDOG][NL];
 #pragma unroll
         for (int lvl = 0; lvl < NDOG; lvl++)
 #pragma unroll
-            for (int k = 0; k < NR; k++) {
-                const int gy = min(y0 - 1 + min(ty + 4 * k, EX_TH + 1), h - 1);
-                const double *row = D + (size_t)lvl * plane + (size_t)gy * w;
-                v[lvl][k] = row[gx];
-                v2[lvl][k] = row[gx2];  // the two halo columns on the right (same cache line for all lanes)
-            }
+            for (int u = 0; u < NL; u++) v[lvl][u] = D[(size_t)lvl * plane + goff[u]];
 #pragma unroll
         for (int lvl = 0; lvl < NDOG; lvl++)
 #pragma unroll
-            for (int k = 0; k < NR; k++) {
-                const int r = ty + 4 * k;
-                if (r < EX_TH + 2) {
-                    s[lvl][r][x] = v[lvl][k];
-                    if (x < 2) s[lvl][r][EX_TW + x] = v2[lvl][k];
-                }
-            }
+            for (int u = 0; u < NL; u++) (&s[lvl][0][0])[soff[u]] = v[lvl][u];
     }
     __syncthreads();
     const double threshold = floor(0.5 * CONTRAST_THRESHOLD / SCALES * 255);  // sift.cpp:266
     const int j = x0 + x;
+    // A positive centre must be >= its 26 neighbours, a negative one <= them
+    // (sift.cpp:275-280), i.e. equal to the maximum (minimum) of the 3x3x3 block.
+    // The block extremes are built separably: per level the 3-wide row
+    // maximum/minimum of six tile rows, then the 3-tall column one for this
+    // thread's four consecutive pixels; the level loop keeps the last three levels.
+    constexpr int RY = EX_TH / 4;  // consecutive rows per thread
+    const int yb = ty * RY;       // first row of this thread (tile coordinates)
+    double vmax[3][RY], vmin[3][RY], centre[2][RY];
 #pragma unroll
-    for (int q = 0; q < EX_TH / 4; q++) {
-        const int y = ty + 4 * q;
-        const int i = y0 + y;
-        const bool inside = (j < w - BORDER) && (i < h - BORDER);
-        for (int img = 1; img <= SCALES; img++) {
-            bool is_ext = false;
-            const double c = s[img][y + 1][x + 1];
-            if (inside && fabs(c) > threshold) {  // sift.cpp:268
-                // A negative centre must be a minimum, a positive one a maximum
-                // (sift.cpp:275-280; |c| > threshold so c != 0).  Flipping the sign
-                // bit of everything when c < 0 turns both cases into "c >= all".
-                const unsigned long long flip = c < 0 ? 0x8000000000000000ull : 0ull;
-                const double cf = __longlong_as_double(__double_as_longlong(c) ^ flip);
-                bool ok = true;
+    for (int lvl = 0; lvl < NDOG; lvl++) {
+        double hmax[RY + 2], hmin[RY + 2], mid[RY + 2];
 #pragma unroll
-                for (int k = -1; k <= 1; k++)
+        for (int r = 0; r < RY + 2; r++) {
+            const double a = s[lvl][yb + r][x], b = s[lvl][yb + r][x + 1], c = s[lvl][yb + r][x + 2];
+            mid[r] = b;
+            hmax[r] = fmax(fmax(a, b), c);
+            hmin[r] = fmin(fmin(a, b), c);
+        }
 #pragma unroll
-                    for (int a = 0; a < 3; a++)
+        for (int q = 0; q < RY; q++) {
+            vmax[lvl % 3][q] = fmax(fmax(hmax[q], hmax[q + 1]), hmax[q + 2]);
+            vmin[lvl % 3][q] = fmin(fmin(hmin[q], hmin[q + 1]), hmin[q + 2]);
+        }
+        if (lvl >= 2) {
+            const int img = lvl - 1;  // levels img-1, img, img+1 are in the window
 #pragma unroll
-                        for (int b = 0; b < 3; b++) {
-                            const double v = s[img + k][y + a][x + b];
-                            ok &= cf >= __longlong_as_double(__double_as_longlong(v) ^ flip);
-                        }
-                is_ext = ok;
-            }
-            const int slot = wave_append(is_ext, &counters[f].candidates);
-            if (slot >= 0) {
-                if (slot < cand_cap) {
-                    Candidate cd = {oct, img, i, j};
-                    cand[(size_t)f * cand_cap + slot] = cd;
-                } else {
-                    counters[f].overflow = 1;
+            for (int q = 0; q < RY; q++) {
+                const int i = y0 + yb + q;
+                const bool inside = (j < w - BORDER) && (i < h - BORDER);
+                const double c = centre[lvl & 1][q];
+                const double hi = fmax(fmax(vmax[0][q], vmax[1][q]), vmax[2][q]);
+                const double lo = fmin(fmin(vmin[0][q], vmin[1][q]), vmin[2][q]);
+                const bool is_ext = inside && fabs(c) > threshold && (c > 0 ? c >= hi : c <= lo);  // sift.cpp:268
+                const int slot = wave_append(is_ext, &counters[f].candidates);
+                if (slot >= 0) {
+                    if (slot < cand_cap) {
+                        Candidate cd = {oct, img, i, j};
+                        cand[(size_t)f * cand_cap + slot] = cd;
+                    } else {
+                        counters[f].overflow = 1;
+                    }
                 }
             }
         }
+        // this level is the centre of the next test
+#pragma unroll
+        for (int q = 0; q < RY; q++) centre[(lvl + 1) & 1][q] = mid[q + 1];
     }
 }
 
