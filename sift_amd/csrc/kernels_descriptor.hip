@@ -149,6 +149,9 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                     g[r] = image[(size_t)yy * width + xx];  // sift.cpp:507-510
                     wj[r] = sm.wtab[min(abs(j), 255)];
                 }
+                // keep the compiler from sinking a load into the branch that consumes it
+#pragma unroll
+                for (int r = 0; r < ROWS_IN_FLIGHT; r++) asm volatile("" : "+v"(g[r].mag), "+v"(g[r].ori), "+v"(wj[r]));
 #pragma unroll
                 for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
                     const int j = jlo[r] + c + lane;

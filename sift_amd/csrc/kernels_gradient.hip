@@ -7,6 +7,7 @@
 // arctangent once per pixel instead of once per window sample removes most of
 // the transcendental work of those stages; the values are the same.
 #include "angle_table.h"
+#include "atan2_fast.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -14,19 +15,21 @@ namespace sa {
 
 namespace {
 
+__device__ const double kAtanKnots[33][2] = SA_ATAN_KNOTS;
+
 // Direction in degrees, (atan2(dy,dx)*180)/PI, as host libm would produce it.
 // The orientation histogram rounds direction*36/360 to the nearest bin, which
 // is discontinuous at the 36 boundaries (5 + 10 m degrees), and images with
 // exact diagonal symmetry put strong gradients within an ulp of them, where
 // the last bit of atan2 picks the bin.  Host libm's atan2 is correctly rounded
-// there; the device library's is good to an ulp or two.  So when the fast
-// result lands within 1e-9 bins of a boundary, the angle is recomputed as
-// boundary + atan(cross/dot) against a double-double table of the boundary
-// directions, which rounds correctly.
-__device__ __forceinline__ double direction_degrees(double dy, double dx) {
-    double a = atan2(dy, dx);
-    double orientation = (a * 180) / PI;
-    const double v = (orientation * BINS) / 360;
+// there; atan2_fast is good to an ulp.  So when the fast result lands within
+// 1e-9 bins of a boundary, the angle is recomputed as boundary +
+// atan(cross/dot) against a double-double table of the boundary directions,
+// which rounds correctly.  `knots` is the LDS copy of kAtanKnots.
+__device__ __forceinline__ double direction_degrees(double dy, double dx, const double (*knots)[2]) {
+    double a = atan2_fast(dy, dx, knots);
+    double orientation = div_pi(a * 180);
+    const double v = orientation * (BINS / 360.0);
     const double fl = floor(v);
     if (fabs(v - fl - 0.5) < 1e-9) {
         const int m = (int)fl;
@@ -39,7 +42,7 @@ __device__ __forceinline__ double direction_degrees(double dy, double dx) {
             const double dot = dx * T[2] + dy * T[4];
             const double delta = cross / dot;  // |delta| < 1e-9: atan(delta) == delta to 1e-27
             a = T[0] + (T[1] + delta);
-            orientation = (a * 180) / PI;
+            orientation = div_pi(a * 180);
         }
     }
     return orientation;
@@ -54,6 +57,9 @@ constexpr int GR_TH = 4 * GR_ROWS;     // rows per workgroup
 
 __global__ __launch_bounds__(256) void k_gradients(const double *__restrict__ gauss, Grad *__restrict__ grad, int w,
                                                     int h) {
+    __shared__ double knots[33][2];
+    if (threadIdx.x < 66) (&knots[0][0])[threadIdx.x] = (&kAtanKnots[0][0])[threadIdx.x];
+    __syncthreads();
     const TileId tile = xcd_tile_id();
     const int x = tile.x * 64 + (threadIdx.x & 63);
     const int y0 = tile.y * GR_TH + (threadIdx.x >> 6) * GR_ROWS;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256) void k_gradients(const double *__restrict__ ga
             const double dx = r[k] - l[k];
             const double dy = c[k] - c[k + 2];
             g.mag = sqrt(dx * dx + dy * dy);
-            g.ori = direction_degrees(dy, dx);
+            g.ori = direction_degrees(dy, dx, knots);
         }
         G[(size_t)y * w + x] = g;
     }
