@@ -33,7 +33,6 @@ int main() {
     auto check = [&](double y, double x) {
         const double want = atan2(y, x), got = sa::atan2_fast(y, x, kKnots);
         const double u = ulps(got, want);
-        if (u > 4 && worst <= 4) printf("big error: y=%a x=%a got %.17g want %.17g\n", y, x, got, want);
         if (u > worst) worst = u;
         diff += got != want;
         const double wd = (want * 180) / PI, gd = sa::div_pi(got * 180);

@@ -141,3 +141,21 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                     text = open(os.path.join(dirpath, f), errors="replace").read()
                     assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_fast_atan2_is_within_two_ulps_of_libm(tmp_path):
+    """sift_amd/csrc/atan2_fast.h compiled for the host (same fma sequence as on the GPU, the
+    hardware reciprocal estimate replaced by a float one) against glibc's atan2, and its
+    division by pi against the IEEE division of (a*180)/PI (sift.cpp:415)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "atan2_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "sift_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "atan2_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "div_pi mismatch" not in out
+    m = re.search(r"samples (\d+) max_ulp ([\d.]+) not_identical (\d+) max_ulp_deg ([\d.]+)", out)
+    assert m, out
+    assert int(m.group(1)) > 4_000_000
+    assert float(m.group(2)) <= 2.0
+    assert float(m.group(4)) <= 3.0
