@@ -32,12 +32,15 @@ namespace {
 
 constexpr int TW = 64;   // strip width (outputs)
 constexpr int MCH = 32;  // rows per step
-constexpr int CX = 8;    // consecutive outputs per thread in the row pass
-constexpr int CY = 8;    // consecutive outputs per thread in the column pass
-constexpr int NTHREADS = 256;
 
+// Threads per workgroup: 256 (8 consecutive outputs per thread in either pass) for the short
+// filters, 512 (4 outputs per thread, half the registers, twice the waves per SIMD) for the
+// long ones, whose loops are bound by fp64 issue and need the extra waves to stay busy.
 template <int R>
 struct MarchGeom {
+    static constexpr int NTHREADS = 512;
+    static constexpr int CX = TW / (NTHREADS / MCH);   // consecutive outputs per thread in the row pass
+    static constexpr int CY = MCH / (NTHREADS / TW);   // consecutive outputs per thread in the column pass
     static constexpr int COLS = TW + 2 * R;
     static constexpr int PIN = COLS | 1;   // odd pitch: lane<->row reads are conflict-free
     static constexpr int RING = MCH + 2 * R;
@@ -82,6 +85,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                                       double *__restrict__ nxt, int w, int h, int nw, int nh, int strip_h,
                                       const Taps &taps, double *smem, const TileId tile) {
     using G = MarchGeom<R>;
+    constexpr int NTHREADS = G::NTHREADS, CX = G::CX, CY = G::CY;
     static_assert(R < MCH, "the centre rows of one step lie in the last two staging buffers");
     double *ring = smem + 2 * MCH * G::PIN;
     const int tid = threadIdx.x;
@@ -124,7 +128,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
 #pragma unroll
             for (int k = 0; k < CX + 2 * R; k++) v[k] = p[k];
             double *q = ring + ((MCH * s + row) % G::RING) * G::PR + cx * CX;
-            // eight independent accumulation chains, advanced one tap at a time
+            // independent accumulation chains, advanced one tap at a time
             double acc[CX];
 #pragma unroll
             for (int m = 0; m < CX; m++) acc[m] = taps.c[0] * v[m];
@@ -187,7 +191,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
 
 // One blur level of one octave for every frame of the batch.
 template <int R>
-__global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restrict__ in, double *__restrict__ out,
+__global__ __launch_bounds__(MarchGeom<R>::NTHREADS) void k_blur_march(const double *__restrict__ in, double *__restrict__ out,
                                                           double *__restrict__ dog, double *__restrict__ next, int w,
                                                           int h, int nw, int nh, size_t in_frame_stride,
                                                           size_t dog_frame_stride, size_t next_frame_stride,
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(NTHREADS) void k_blur_march(const double *__restric
 
 // gray u8 -> double -> 2x bilinear upsample -> base blur (sift.cpp:30, :40-42).
 template <int R>
-__global__ __launch_bounds__(NTHREADS) void k_base_march(const uint8_t *__restrict__ frames, int W, int H,
+__global__ __launch_bounds__(MarchGeom<R>::NTHREADS) void k_base_march(const uint8_t *__restrict__ frames, int W, int H,
                                                           double *__restrict__ out, size_t out_frame_stride,
                                                           int strip_h, Taps taps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -244,7 +248,7 @@ void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nfram
     dim3 grid;
     int strip_h;
     strip_grid(w, h, nframes, grid, strip_h);
-    hipLaunchKernelGGL(k_blur_march<R>, grid, dim3(NTHREADS), MarchGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h,
+    hipLaunchKernelGGL(k_blur_march<R>, grid, dim3(MarchGeom<R>::NTHREADS), MarchGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h,
                        nw, nh, (size_t)IMAGES * plane, (size_t)NDOG * plane, next_stride, strip_h, taps);
 }
 
@@ -297,7 +301,7 @@ void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframe
     dim3 grid;
     int strip_h;
     strip_grid(w, h, nframes, grid, strip_h);
-    hipLaunchKernelGGL(k_base_march<5>, grid, dim3(NTHREADS), MarchGeom<5>::LDS_BYTES, st, frames, W, H, p.gauss[0],
+    hipLaunchKernelGGL(k_base_march<5>, grid, dim3(MarchGeom<5>::NTHREADS), MarchGeom<5>::LDS_BYTES, st, frames, W, H, p.gauss[0],
                        (size_t)IMAGES * w * h, strip_h, taps);
 }
 
