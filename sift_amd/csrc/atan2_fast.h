@@ -46,7 +46,11 @@ SA_HD double atan2_fast(double y, double x, const double (*knots)[2]) {
     }
     double r = 0.0;
     if (mx > 0.0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float tf = (float)mn * __builtin_amdgcn_rcpf((float)mx);
+#else
         const float tf = (float)mn / (float)mx;
+#endif
         int i = (int)rintf(tf * 32.0f);
         i = i < 0 ? 0 : (i > 32 ? 32 : i);
         const double c = (double)i * 0.03125;
