@@ -1,11 +1,11 @@
 // 4x4x8 descriptors: get_descriptors_parallel::operator() (sift.cpp:464-584).
 //
-// One 256-thread workgroup per keypoint; workgroups pull keypoints from a
-// per-frame cursor.  Each wave takes every fourth row of the
+// One 128-thread workgroup per keypoint; workgroups pull keypoints from a
+// per-frame cursor.  Each of its two waves takes every second row of the
 // (2*half_width+1)^2 window.  For a row, the columns that can pass the
 // rotated-window test of sift.cpp:503 form an interval (two strips
-// -1 < s*j + B < 4 intersected); the wave sweeps only that interval, widened by one pixel, with
-// lanes on consecutive columns (coalesced reads), and every sample still takes
+// -1 < s*j + B < 4 intersected); the wave sweeps only that interval, widened by
+// one pixel, with lanes on consecutive columns (coalesced reads), and every sample still takes
 // the exact test.  A sample's gradient magnitude and direction come from the
 // precomputed gradient plane of the keypoint's Gaussian level, and its
 // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) is the product of two entries of a
@@ -16,7 +16,7 @@
 // atomics.  Only the inner 4x4x8 bins are kept (the border ring of the 6x6x8
 // tensor is discarded by sift.cpp:557-563, so contributions to it are never
 // issued), and there is one 128-bin copy per (wave, lane & 7) so that
-// neighbouring pixels, which mostly share a bin, rarely collide.  The 32
+// neighbouring pixels, which mostly share a bin, rarely collide.  The 16
 // copies are summed in fixed order, then normalised, clipped at 0.2*norm,
 // scaled by 512 and rounded exactly as sift.cpp:564-573 does.  Output is one
 // byte per bin (values 0..255; at most 102 in practice).
@@ -29,9 +29,10 @@ namespace {
 
 constexpr int DBINS = 8;
 constexpr int INNER = WINDOW_WIDTH * WINDOW_WIDTH * DBINS;  // 128
-constexpr int NWAVES = 4;
+constexpr int NWAVES = 2;
 constexpr int COPIES_PER_WAVE = 8;
 constexpr int NT = NWAVES * 64;  // threads per workgroup
+static_assert(NT >= INNER, "one thread per bin in the normalisation");
 constexpr int ROWS_IN_FLIGHT = 4;
 constexpr int NCOPY = NWAVES * COPIES_PER_WAVE;
 constexpr int CSTRIDE = INNER + 1;  // copies start one LDS bank pair apart, so equal bins of different copies do not share a bank
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
         double *T = sm.tensor[wv * COPIES_PER_WAVE + (lane & (COPIES_PER_WAVE - 1))];
         // image bounds on the column: 0 < pt_x + j < width - 1 (sift.cpp:506)
         const int jmin = max(-half_width, 1 - pt_x), jmax = min(half_width, width - 2 - pt_x);
-        // Each wave takes rows wv, wv+4, ...; ROWS_IN_FLIGHT rows are handled together so
+        // Each wave takes rows wv, wv+NWAVES, ...; ROWS_IN_FLIGHT rows are handled together so
         // that their gradient loads are all issued before the first one is consumed.
         for (int i0 = -half_width + wv; i0 <= half_width; i0 += NWAVES * ROWS_IN_FLIGHT) {
             int jlo[ROWS_IN_FLIGHT], jhi[ROWS_IN_FLIGHT];
