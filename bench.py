@@ -42,10 +42,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--pool", type=int, default=4, help="distinct batches resident in HBM, cycled over steps")
+    ap.add_argument("--pool", type=int, default=2, help="distinct batches resident in HBM, cycled over steps")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams) per GPU; the batch is split evenly between them")
     ap.add_argument("--knn-queries", type=int, default=262144)
@@ -164,9 +164,11 @@ def main():
         taps = {"blur_l1": 11, "blur_l2": 13, "blur_l3": 17, "blur_l4": 21, "blur_l5": 27}[dom]
         traffic = None
         tpath = os.path.join(HERE, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (W, H) == (1920, 1080):
+            # measured with PMC counters on 1080p batches; bytes per launch scale with the frames per launch
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj[dom] * B / tj["_frames_per_launch"]
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "k_blur_march<%d> (%d taps)" % (taps // 2, taps),

@@ -14,12 +14,12 @@ if [ $rc -ne 0 ]; then tail -60 $O/gputests_full.log; exit $rc; fi
 timeout -k 10 300 python -u -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 || { tail -30 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log
 rm -rf $O/prof_bench $O/pmc_fetch $O/pmc_write $O/pmc_cal_fetch $O/pmc_cal_write
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o x -- python3 scripts/prof_extract.py 16 > $O/pmc_fetch.log 2>&1 || { tail -20 $O/pmc_fetch.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o x -- python3 scripts/prof_extract.py 16 > $O/pmc_write.log 2>&1 || { tail -20 $O/pmc_write.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o x -- python3 scripts/prof_extract.py 64 > $O/pmc_fetch.log 2>&1 || { tail -20 $O/pmc_fetch.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o x -- python3 scripts/prof_extract.py 64 > $O/pmc_write.log 2>&1 || { tail -20 $O/pmc_write.log; exit 1; }
 timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_cal_fetch -o x -- scripts/ubench/copy8 1024 > $O/pmc_cal_fetch.log 2>&1 || { tail -20 $O/pmc_cal_fetch.log; exit 1; }
 timeout -s KILL 60 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_cal_write -o x -- scripts/ubench/copy8 1024 > $O/pmc_cal_write.log 2>&1 || { tail -20 $O/pmc_cal_write.log; exit 1; }
 for d in pmc_fetch pmc_write pmc_cal_fetch pmc_cal_write; do echo "== $d"; python scripts/pmc_summary.py $O/$d; done > $O/pmc_all.txt
-python scripts/make_traffic.py $O > $O/traffic_summary.txt && cp profiles/traffic.json $O/traffic.json
+python scripts/make_traffic.py $O 64 > $O/traffic_summary.txt && cp profiles/traffic.json $O/traffic.json
 tail -12 $O/traffic_summary.txt
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 bench.py > $O/bench_profiled.json 2> $O/bench_profiled.err || { tail -20 $O/bench_profiled.err; exit 1; }
 python scripts/bench_summary.py $O/bench_profiled.json

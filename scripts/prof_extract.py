@@ -3,7 +3,7 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np
 import sift_amd as S
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 W, H = 1920, 1080
 ctx = S.Context(0)
 b = ctx.batch(W, H, B)
