@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--knn-queries", type=int, default=262144)
     ap.add_argument("--knn-train", type=int, default=1 << 20)
     ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--force-sharded-knn", action="store_true",
+                    help="run the sharded-matcher leg even with one rank (exercises the RCCL exchange path)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
@@ -134,6 +136,40 @@ def main():
                    "frames_per_gpu_per_step": B, "streams_per_gpu": nstreams, "distinct_batches_in_hbm": npool,
                    "keypoints_per_frame_mean": kp_mean},
     }
+
+    # ---- sharded matcher: every rank holds knn_train rows of the train set and all queries;
+    # local top-2, one all-to-all of 16 B per query per peer, merge on the owner of each slice
+    if (world > 1 or args.force_sharded_knn) and not args.no_knn:
+        if dist is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        from sift_amd.dist import sharded_knn2
+        nq, nt_r = args.knn_queries, args.knn_train
+        t_shard = torch.from_numpy(S.synth_descriptors(5 + 97 * rank, nt_r)).cuda()
+        q_all = torch.from_numpy(S.synth_queries(6, S.synth_descriptors(5, min(nt_r, 1 << 16)), nq)).cuda()
+        sharded_knn2(q_all, t_shard, rank * nt_r, ctx=ctx, gather=False)      # warm-up (RCCL channels, kernels)
+        torch.cuda.synchronize()
+        dist.barrier()
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            merged, accept, (lo, hi) = sharded_knn2(q_all, t_shard, rank * nt_r, ctx=ctx, gather=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # property check on this rank's slice: best distance <= second best, indices inside the global train set
+        m = merged.cpu().numpy()
+        ok = bool((m[:, 0] <= m[:, 2]).all() and (m[:, 1] >= 0).all() and (m[:, 1] < world * nt_r).all())
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        out["knn_sharded"] = {"queries": nq, "train_total": world * nt_r, "train_per_gpu": nt_r, "ms": dt * 1e3,
+                              "pairs_per_s": nq * world * nt_r / dt, "exchange": "all_to_all_single, 16 B per query per peer",
+                              "sane": bool(int(okt.item()))}
+        del t_shard, q_all, merged, accept
 
     if rank == 0:
         # ---- per-kernel device time (HIP events on the engine's stream) ---------
