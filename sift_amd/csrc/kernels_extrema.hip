@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
     const int x0 = BORDER + tile.x * EX_TW, y0 = BORDER + tile.y * EX_TH;
     const size_t plane = (size_t)w * h;
     const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
-    const int x = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // a wave is one row group
     {
         // All loads of the tile are issued before the first LDS write, with row and
         // column indices clamped into the image instead of branching: tested pixels

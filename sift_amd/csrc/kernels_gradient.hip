@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_gradients(const double *__restrict__ ga
     __syncthreads();
     const TileId tile = xcd_tile_id();
     const int x = tile.x * 64 + (threadIdx.x & 63);
-    const int y0 = tile.y * GR_TH + (threadIdx.x >> 6) * GR_ROWS;
+    const int y0 = tile.y * GR_TH + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * GR_ROWS;  // a wave is one row group
     if (y0 >= h) return;
     const int frame = tile.z / SCALES, layer = tile.z % SCALES + 1;
     const size_t plane = (size_t)w * h;

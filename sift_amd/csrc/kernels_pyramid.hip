@@ -109,7 +109,11 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
         const int v0 = ys - R + MCH * s;
 #pragma unroll
         for (int u = 0; u < G::NLOAD; u++) {
-            if (pf_row[u] >= 0) pf[u] = source(reflect101(v0 + pf_row[u], h), pf_gx[u]);
+            if (pf_row[u] >= 0) {
+                int gy = v0 + pf_row[u];
+                if ((unsigned)gy >= (unsigned)h) gy = reflect101(gy, h);  // only the strips at the image edge
+                pf[u] = source(gy, pf_gx[u]);
+            }
         }
     };
 
@@ -142,7 +146,8 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
         }
         __syncthreads();
         {   // column pass: lane <-> column, 8 consecutive output rows per thread
-            const int x = tid & (TW - 1), cy = tid / TW;
+            // a wave is one 64-column row group: its ring slots, centre rows and output rows are scalars
+            const int x = tid & (TW - 1), cy = __builtin_amdgcn_readfirstlane(tid / TW);
             const int rel0 = MCH * s + cy * CY - R;  // strip-relative index of the first output row
             const int y0 = ys - R + rel0;            // its image row
             const int gx = tx0 + x;
