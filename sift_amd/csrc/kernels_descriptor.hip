@@ -48,6 +48,13 @@ __device__ __forceinline__ void clip_strip(double s, double is, bool flat, doubl
     hi = fmin(hi, fmax(j1, j2));
 }
 
+// Value of `v` in lane `src` (wave-uniform index) for every lane.
+__device__ __forceinline__ double lane_broadcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 struct DescShared {
     double wtab[256];
     double vals[INNER];
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
     __shared__ DescShared sm;
     const int f = blockIdx.y;
     const int tid = threadIdx.x;
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int n = counters[f].keypoints;
     if (n > kp_cap) n = kp_cap;
     for (;;) {
@@ -107,97 +114,108 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
         double *T = sm.tensor[wv * COPIES_PER_WAVE + (lane & (COPIES_PER_WAVE - 1))];
         // image bounds on the column: 0 < pt_x + j < width - 1 (sift.cpp:506)
         const int jmin = max(-half_width, 1 - pt_x), jmax = min(half_width, width - 2 - pt_x);
-        // Each wave takes rows wv, wv+NWAVES, ...; ROWS_IN_FLIGHT rows are handled together so
-        // that their gradient loads are all issued before the first one is consumed.
-        for (int i0 = -half_width + wv; i0 <= half_width; i0 += NWAVES * ROWS_IN_FLIGHT) {
-            int jlo[ROWS_IN_FLIGHT], jhi[ROWS_IN_FLIGHT];
-            double Bu[ROWS_IN_FLIGHT], Bv[ROWS_IN_FLIGHT], wi[ROWS_IN_FLIGHT];
-            int longest = 0;
-#pragma unroll
-            for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
-                const int i = i0 + r * NWAVES;
+        // Each wave takes rows wv, wv+NWAVES, ...  Row set-up (column interval, bin offsets, row
+        // weight) is done for 64 rows at once, one row per lane, and handed to the whole wave
+        // through readlane; ROWS_IN_FLIGHT rows are then swept together so that their gradient
+        // loads are all issued before the first one is consumed.
+        for (int ib = -half_width + wv; ib <= half_width; ib += NWAVES * 64) {
+            int my_jlo = 0, my_jhi = -1;
+            double my_Bu, my_Bv, my_wi = 0.0;
+            {
+                const int i = ib + lane * NWAVES;
                 const int win_row = pt_y + i;
-                jlo[r] = 0;
-                jhi[r] = -1;
-                Bu[r] = (cosv * i) * inv_hw + half_bins;
-                Bv[r] = (sinv * i) * inv_hw + half_bins;
-                wi[r] = 0.0;
+                my_Bu = (cosv * i) * inv_hw + half_bins;
+                my_Bv = (sinv * i) * inv_hw + half_bins;
                 if (i <= half_width && win_row > 0 && win_row < height - 1) {  // sift.cpp:506 (rows)
                     double lo = jmin, hi = jmax;
-                    clip_strip(su, isu, flat_u, Bu[r], lo, hi);
-                    clip_strip(sv, isv, flat_v, Bv[r], lo, hi);
+                    clip_strip(su, isu, flat_u, my_Bu, lo, hi);
+                    clip_strip(sv, isv, flat_v, my_Bv, lo, hi);
                     if (hi >= lo - 2) {
-                        jlo[r] = max(jmin, (int)floor(lo) - 1);
-                        jhi[r] = min(jmax, (int)ceil(hi) + 1);
+                        my_jlo = max(jmin, (int)floor(lo) - 1);
+                        my_jhi = min(jmax, (int)ceil(hi) + 1);
                     }
-                    wi[r] = use_tab ? sm.wtab[abs(i)] : exp(wscale * (double)(i * i));
+                    my_wi = use_tab ? sm.wtab[min(abs(i), 255)] : exp(wscale * (double)(i * i));
                 }
-                longest = max(longest, jhi[r] - jlo[r] + 1);
             }
-            for (int c = 0; c < longest; c += 64) {
-                // Everything the four rows read (gradients from memory, column weights from the
-                // LDS table) is requested here, before the first atomic of the group: an LDS read
-                // issued between atomics would have to wait for all of them.  The loads are
-                // unconditional, at addresses clamped into the plane, so that all four are in
-                // flight together; lanes outside their row's interval discard what they read.
-                Grad g[ROWS_IN_FLIGHT];
-                double wj[ROWS_IN_FLIGHT];
+            for (int g0 = 0; g0 < 64 && ib + g0 * NWAVES <= half_width; g0 += ROWS_IN_FLIGHT) {
+                const int i0 = ib + g0 * NWAVES;
+                int jlo[ROWS_IN_FLIGHT], jhi[ROWS_IN_FLIGHT];
+                double Bu[ROWS_IN_FLIGHT], Bv[ROWS_IN_FLIGHT], wi[ROWS_IN_FLIGHT];
+                int longest = 0;
 #pragma unroll
                 for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
-                    const int j = jlo[r] + c + lane;
-                    const int yy = min(max(pt_y + i0 + r * NWAVES, 0), height - 1);
-                    const int xx = min(max(pt_x + j, 0), width - 1);
-                    g[r] = image[(size_t)yy * width + xx];  // sift.cpp:507-510
-                    wj[r] = sm.wtab[min(abs(j), 255)];
+                    jlo[r] = __builtin_amdgcn_readlane(my_jlo, g0 + r);
+                    jhi[r] = __builtin_amdgcn_readlane(my_jhi, g0 + r);
+                    Bu[r] = lane_broadcast(my_Bu, g0 + r);
+                    Bv[r] = lane_broadcast(my_Bv, g0 + r);
+                    wi[r] = lane_broadcast(my_wi, g0 + r);
+                    longest = max(longest, jhi[r] - jlo[r] + 1);
                 }
-                // keep the compiler from sinking a load into the branch that consumes it
+                for (int c = 0; c < longest; c += 64) {
+                    // Everything the four rows read (gradients from memory, column weights from the
+                    // LDS table) is requested here, before the first atomic of the group: an LDS read
+                    // issued between atomics would have to wait for all of them.  The loads are
+                    // unconditional, at addresses clamped into the plane, so that all four are in
+                    // flight together; lanes outside their row's interval discard what they read.
+                    Grad g[ROWS_IN_FLIGHT];
+                    double wj[ROWS_IN_FLIGHT];
 #pragma unroll
-                for (int r = 0; r < ROWS_IN_FLIGHT; r++) asm volatile("" : "+v"(g[r].mag), "+v"(g[r].ori), "+v"(wj[r]));
+                    for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
+                        const int j = jlo[r] + c + lane;
+                        const int yy = min(max(pt_y + i0 + r * NWAVES, 0), height - 1);
+                        const int xx = min(max(pt_x + j, 0), width - 1);
+                        g[r] = image[(size_t)yy * width + xx];  // sift.cpp:507-510
+                        wj[r] = sm.wtab[min(abs(j), 255)];
+                    }
+                    // keep the compiler from sinking a load into the branch that consumes it
 #pragma unroll
-                for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
-                    const int j = jlo[r] + c + lane;
-                    if (j > jhi[r]) continue;
-                    const double dj = (double)j;
-                    const double bin_row = su * dj + Bu[r];
-                    const double bin_col = sv * dj + Bv[r];
-                    if (!(bin_row > -1 && bin_col > -1 && bin_row < WINDOW_WIDTH && bin_col < WINDOW_WIDTH)) continue;
-                    // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) (sift.cpp:512-517) as a product of two table entries
-                    const double wcol = use_tab ? wj[r] : exp(wscale * (double)(j * j));
-                    const double magnitude = g[r].mag * (wi[r] * wcol);                  // sift.cpp:518
-                    const double orientation = g[r].ori * bins_per_degree - ang_bins;  // sift.cpp:519
-                    const double fr = floor(bin_row), fc = floor(bin_col), fo = floor(orientation);
-                    const int row_bin = (int)fr, col_bin = (int)fc;
-                    const double row_pr = bin_row - fr, col_pr = bin_col - fc, ori_pr = orientation - fo;
-                    const int ob0 = (int)fo & (DBINS - 1), ob1 = ((int)fo + 1) & (DBINS - 1);
-                    // trilinear split (sift.cpp:527-551): each step peels the upper share off the lower one
-                    const double m1 = magnitude * row_pr, m0 = magnitude - m1;
-                    const double m01 = m0 * col_pr, m00 = m0 - m01;
-                    const double m11 = m1 * col_pr, m10 = m1 - m11;
-                    // cell (row_bin + a, col_bin + b) of the inner 4x4 grid; the border ring is dropped
-                    double *cell = T + (row_bin * WINDOW_WIDTH + col_bin) * DBINS;
-                    const bool r0 = (unsigned)row_bin < (unsigned)WINDOW_WIDTH;
-                    const bool r1 = (unsigned)(row_bin + 1) < (unsigned)WINDOW_WIDTH;
-                    const bool c0 = (unsigned)col_bin < (unsigned)WINDOW_WIDTH;
-                    const bool c1 = (unsigned)(col_bin + 1) < (unsigned)WINDOW_WIDTH;
-                    if (r0 && c0) {
-                        const double hi = m00 * ori_pr;
-                        atomicAdd(cell + ob0, m00 - hi);
-                        atomicAdd(cell + ob1, hi);
-                    }
-                    if (r0 && c1) {
-                        const double hi = m01 * ori_pr;
-                        atomicAdd(cell + DBINS + ob0, m01 - hi);
-                        atomicAdd(cell + DBINS + ob1, hi);
-                    }
-                    if (r1 && c0) {
-                        const double hi = m10 * ori_pr;
-                        atomicAdd(cell + WINDOW_WIDTH * DBINS + ob0, m10 - hi);
-                        atomicAdd(cell + WINDOW_WIDTH * DBINS + ob1, hi);
-                    }
-                    if (r1 && c1) {
-                        const double hi = m11 * ori_pr;
-                        atomicAdd(cell + (WINDOW_WIDTH + 1) * DBINS + ob0, m11 - hi);
-                        atomicAdd(cell + (WINDOW_WIDTH + 1) * DBINS + ob1, hi);
+                    for (int r = 0; r < ROWS_IN_FLIGHT; r++) asm volatile("" : "+v"(g[r].mag), "+v"(g[r].ori), "+v"(wj[r]));
+#pragma unroll
+                    for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
+                        const int j = jlo[r] + c + lane;
+                        if (j > jhi[r]) continue;
+                        const double dj = (double)j;
+                        const double bin_row = su * dj + Bu[r];
+                        const double bin_col = sv * dj + Bv[r];
+                        if (!(bin_row > -1 && bin_col > -1 && bin_row < WINDOW_WIDTH && bin_col < WINDOW_WIDTH)) continue;
+                        // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) (sift.cpp:512-517) as a product of two table entries
+                        const double wcol = use_tab ? wj[r] : exp(wscale * (double)(j * j));
+                        const double magnitude = g[r].mag * (wi[r] * wcol);                  // sift.cpp:518
+                        const double orientation = g[r].ori * bins_per_degree - ang_bins;  // sift.cpp:519
+                        const double fr = floor(bin_row), fc = floor(bin_col), fo = floor(orientation);
+                        const int row_bin = (int)fr, col_bin = (int)fc;
+                        const double row_pr = bin_row - fr, col_pr = bin_col - fc, ori_pr = orientation - fo;
+                        const int ob0 = (int)fo & (DBINS - 1), ob1 = ((int)fo + 1) & (DBINS - 1);
+                        // trilinear split (sift.cpp:527-551): each step peels the upper share off the lower one
+                        const double m1 = magnitude * row_pr, m0 = magnitude - m1;
+                        const double m01 = m0 * col_pr, m00 = m0 - m01;
+                        const double m11 = m1 * col_pr, m10 = m1 - m11;
+                        // cell (row_bin + a, col_bin + b) of the inner 4x4 grid; the border ring is dropped
+                        double *cell = T + (row_bin * WINDOW_WIDTH + col_bin) * DBINS;
+                        const bool r0 = (unsigned)row_bin < (unsigned)WINDOW_WIDTH;
+                        const bool r1 = (unsigned)(row_bin + 1) < (unsigned)WINDOW_WIDTH;
+                        const bool c0 = (unsigned)col_bin < (unsigned)WINDOW_WIDTH;
+                        const bool c1 = (unsigned)(col_bin + 1) < (unsigned)WINDOW_WIDTH;
+                        if (r0 && c0) {
+                            const double hi = m00 * ori_pr;
+                            atomicAdd(cell + ob0, m00 - hi);
+                            atomicAdd(cell + ob1, hi);
+                        }
+                        if (r0 && c1) {
+                            const double hi = m01 * ori_pr;
+                            atomicAdd(cell + DBINS + ob0, m01 - hi);
+                            atomicAdd(cell + DBINS + ob1, hi);
+                        }
+                        if (r1 && c0) {
+                            const double hi = m10 * ori_pr;
+                            atomicAdd(cell + WINDOW_WIDTH * DBINS + ob0, m10 - hi);
+                            atomicAdd(cell + WINDOW_WIDTH * DBINS + ob1, hi);
+                        }
+                        if (r1 && c1) {
+                            const double hi = m11 * ori_pr;
+                            atomicAdd(cell + (WINDOW_WIDTH + 1) * DBINS + ob0, m11 - hi);
+                            atomicAdd(cell + (WINDOW_WIDTH + 1) * DBINS + ob1, hi);
+                        }
                     }
                 }
             }
