@@ -57,9 +57,7 @@ __device__ __forceinline__ double lane_broadcast(double v, int src) {
 
 struct DescShared {
     double wtab[256];
-    double vals[INNER];
-    double red[INNER];
-    double tensor[NCOPY][CSTRIDE];
+    double tensor[NCOPY][CSTRIDE];  // after the copies are summed, its first 2*INNER doubles hold the sums and their squares
     int idx;
 };
 
@@ -222,22 +220,27 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
         }
         __syncthreads();
         // inner 4x4x8 bins (sift.cpp:557-563), copies summed in fixed order
+        double *vals = &sm.tensor[0][0], *red = vals + INNER;
+        double v = 0.0;
         if (tid < INNER) {
-            double v = sm.tensor[0][tid];
+            v = sm.tensor[0][tid];
 #pragma unroll 8
             for (int c = 1; c < NCOPY; c++) v += sm.tensor[c][tid];
-            sm.vals[tid] = v;
-            sm.red[tid] = v * v;
+        }
+        __syncthreads();  // every copy has been read: the tensor's storage is reused below
+        if (tid < INNER) {
+            vals[tid] = v;
+            red[tid] = v * v;
         }
         __syncthreads();
         for (int sft = INNER / 2; sft > 0; sft >>= 1) {
-            if (tid < sft) sm.red[tid] += sm.red[tid + sft];
+            if (tid < sft) red[tid] += red[tid + sft];
             __syncthreads();
         }
         if (tid < INNER) {
-            const double norm = sqrt(sm.red[0]);          // sift.cpp:564-565
+            const double norm = sqrt(red[0]);          // sift.cpp:564-565
             const double thresh = norm * DESCRIPTOR_MAX;  // sift.cpp:566
-            double I = sm.vals[tid];
+            double I = vals[tid];
             I = I > thresh ? thresh : I;
             I /= fmax(norm, EPS);
             I = round(I * 512);
