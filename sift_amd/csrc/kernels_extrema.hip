@@ -29,64 +29,58 @@ __device__ __forceinline__ int wave_append(bool flag, int32_t *counter) {
     return flag ? base + rank : -1;
 }
 
-// is_pixel_extremum (sift.cpp:264-281) for the three scanned layers.  A
-// workgroup stages a 64x16 pixel tile (plus a one-pixel halo) of all five DoG
-// levels in LDS, so every DoG value is read from HBM once; each thread then
-// tests four consecutive pixels of a column in the three scanned layers.
-constexpr int EX_TW = 64, EX_TH = 16;
+// Value of `v` in the lane to the left (from_left) or right of this one; the
+// end lanes of the wave receive an unspecified value.
+template <bool from_left>
+__device__ __forceinline__ double neighbour_lane(double v) {
+    constexpr int ctrl = from_left ? 0x138 : 0x130;  // DPP wave_shr:1 / wave_shl:1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// is_pixel_extremum (sift.cpp:264-281) for the three scanned layers.  A wave
+// owns 62 columns x 4 rows (its first and last lane only carry the halo
+// columns); a thread loads the six rows of its column in all five DoG levels
+// into registers, every load in flight together, and takes its left and right
+// neighbours from the adjacent lanes, so there is no LDS staging and no barrier.
+constexpr int EX_TW = 62, EX_TH = 16;
 
 __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
                                                   FrameCounters *__restrict__ counters) {
-    __shared__ double s[NDOG][EX_TH + 2][EX_TW + 2];
     const int w = p.w[oct], h = p.h[oct];
     const TileId tile = xcd_tile_id();
     const int f = tile.z;
-    const int x0 = BORDER + tile.x * EX_TW, y0 = BORDER + tile.y * EX_TH;
     const size_t plane = (size_t)w * h;
     const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
-    const int x = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // a wave is one row group
-    {
-        // All loads of the tile are issued before the first LDS write, with row and
-        // column indices clamped into the image instead of branching: tested pixels
-        // lie BORDER pixels inside, so a clamped halo value is never compared.
-        constexpr int TILE = (EX_TH + 2) * (EX_TW + 2);
-        constexpr int NL = (TILE + 255) / 256;  // tile elements per thread and level
-        int goff[NL], soff[NL];
+    const int lane = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // a wave is one row group
+    constexpr int RY = EX_TH / 4;  // consecutive rows per thread
+    const int j = BORDER + tile.x * EX_TW + lane - 1;  // this lane's column
+    const int i0 = BORDER + tile.y * EX_TH + ty * RY;  // first tested row of this wave
+    if (i0 >= h - BORDER) return;
+    // Row and column indices are clamped into the image instead of branching: tested
+    // pixels lie BORDER pixels inside, so a clamped halo value is never compared.
+    const int gx = min(j, w - 1);
+    double v[NDOG][RY + 2];
 #pragma unroll
-        for (int u = 0; u < NL; u++) {
-            const int idx = min((int)threadIdx.x + 256 * u, TILE - 1);  // the last few threads repeat the last element
-            const int r = idx / (EX_TW + 2), c = idx - r * (EX_TW + 2);
-            goff[u] = min(y0 - 1 + r, h - 1) * w + min(x0 - 1 + c, w - 1);
-            soff[u] = idx;
-        }
-        double v[NDOG][NL];
+    for (int lvl = 0; lvl < NDOG; lvl++)
 #pragma unroll
-        for (int lvl = 0; lvl < NDOG; lvl++)
-#pragma unroll
-            for (int u = 0; u < NL; u++) v[lvl][u] = D[(size_t)lvl * plane + goff[u]];
-#pragma unroll
-        for (int lvl = 0; lvl < NDOG; lvl++)
-#pragma unroll
-            for (int u = 0; u < NL; u++) (&s[lvl][0][0])[soff[u]] = v[lvl][u];
-    }
-    __syncthreads();
+        for (int r = 0; r < RY + 2; r++) v[lvl][r] = D[(size_t)lvl * plane + (size_t)min(i0 - 1 + r, h - 1) * w + gx];
     const double threshold = floor(0.5 * CONTRAST_THRESHOLD / SCALES * 255);  // sift.cpp:266
-    const int j = x0 + x;
+    const bool column_tested = lane >= 1 && lane <= EX_TW && j < w - BORDER;
     // A positive centre must be >= its 26 neighbours, a negative one <= them
     // (sift.cpp:275-280), i.e. equal to the maximum (minimum) of the 3x3x3 block.
     // The block extremes are built separably: per level the 3-wide row
-    // maximum/minimum of six tile rows, then the 3-tall column one for this
-    // thread's four consecutive pixels; the level loop keeps the last three levels.
-    constexpr int RY = EX_TH / 4;  // consecutive rows per thread
-    const int yb = ty * RY;       // first row of this thread (tile coordinates)
-    double vmax[3][RY], vmin[3][RY], centre[2][RY];
+    // maximum/minimum of six rows, then the 3-tall column one for this thread's
+    // four consecutive pixels; the level loop keeps the last three levels.
+    double vmax[3][RY], vmin[3][RY];
 #pragma unroll
     for (int lvl = 0; lvl < NDOG; lvl++) {
-        double hmax[RY + 2], hmin[RY + 2], mid[RY + 2];
+        double hmax[RY + 2], hmin[RY + 2];
 #pragma unroll
         for (int r = 0; r < RY + 2; r++) {
-            const double a = s[lvl][yb + r][x], b = s[lvl][yb + r][x + 1], c = s[lvl][yb + r][x + 2];
-            mid[r] = b;
+            const double b = v[lvl][r];
+            const double a = neighbour_lane<true>(b), c = neighbour_lane<false>(b);
             hmax[r] = fmax(fmax(a, b), c);
             hmin[r] = fmin(fmin(a, b), c);
         }
@@ -99,12 +93,12 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
             const int img = lvl - 1;  // levels img-1, img, img+1 are in the window
 #pragma unroll
             for (int q = 0; q < RY; q++) {
-                const int i = y0 + yb + q;
-                const bool inside = (j < w - BORDER) && (i < h - BORDER);
-                const double c = centre[lvl & 1][q];
+                const int i = i0 + q;
+                const double c = v[img][q + 1];
                 const double hi = fmax(fmax(vmax[0][q], vmax[1][q]), vmax[2][q]);
                 const double lo = fmin(fmin(vmin[0][q], vmin[1][q]), vmin[2][q]);
-                const bool is_ext = inside && fabs(c) > threshold && (c > 0 ? c >= hi : c <= lo);  // sift.cpp:268
+                const bool is_ext =
+                    column_tested && i < h - BORDER && fabs(c) > threshold && (c > 0 ? c >= hi : c <= lo);  // sift.cpp:268
                 const int slot = wave_append(is_ext, &counters[f].candidates);
                 if (slot >= 0) {
                     if (slot < cand_cap) {
@@ -116,9 +110,6 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
                 }
             }
         }
-        // this level is the centre of the next test
-#pragma unroll
-        for (int q = 0; q < RY; q++) centre[(lvl + 1) & 1][q] = mid[q + 1];
     }
 }
 
