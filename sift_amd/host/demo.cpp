@@ -1,16 +1,16 @@
 // Counterpart of the reference's src/main.cpp up to the match list
 // (main.cpp:22-93): extract features of every image, then match the last image
 // (the reference) against each of the others and report the good matches.
-// Images are binary PGM (P5) or PPM (P6, RGB) files; with real OpenCV one would
-// use cv::imread exactly as main.cpp does.
+// Images are PNG or binary PGM/PPM files, read by sift_io::imread with the
+// conventions of cv::imread (BGR, 8-bit, 3 channels).
 //
 //   sift_demo <image>                 -> keypoints only (main.cpp:28-39)
 //   sift_demo <img1> ... <imgN>       -> match each img against imgN
 #include <cstdio>
-#include <fstream>
 #include <iostream>
 #include <sstream>
 
+#include "image_io.hpp"
 #include "sift.hpp"
 
 // "dir/name.ext" -> "name" (what main.cpp:13-19 passes to the handler as its name)
@@ -20,35 +20,13 @@ static std::string stem_of(const std::string &path) {
     return file.substr(0, file.rfind('.'));
 }
 
-static cv::Mat read_pnm(const std::string &path) {
-    std::ifstream f(path, std::ios::binary);
-    std::string magic;
-    f >> magic;
-    if (magic != "P5" && magic != "P6") return cv::Mat();
-    int w = 0, h = 0, maxv = 0;
-    auto skip = [&] {
-        f >> std::ws;
-        while (f.peek() == '#') { std::string line; std::getline(f, line); f >> std::ws; }
-    };
-    skip(); f >> w; skip(); f >> h; skip(); f >> maxv;
-    f.get();
-    if (!f || w <= 0 || h <= 0 || maxv != 255) return cv::Mat();
-    const int cn = magic == "P6" ? 3 : 1;
-    cv::Mat m(h, w, cn == 3 ? CV_8UC3 : CV_8UC1);
-    f.read(reinterpret_cast<char *>(m.data), (std::streamsize)w * h * cn);
-    if (!f) return cv::Mat();
-    if (cn == 3)  // PPM is RGB; the engine expects BGR like cv::imread
-        for (int i = 0; i < w * h; i++) std::swap(m.data[3 * i], m.data[3 * i + 2]);
-    return m;
-}
-
 int main(int argc, char **argv) {
     if (argc < 2) {
         printf("usage: sift_demo <Image_Path> <Image_Path>\n");
         return -1;
     }
     if (argc == 2) {
-        cv::Mat image = read_pnm(argv[1]);
+        cv::Mat image = sift_io::imread(argv[1]);
         if (!image.data) {
             printf("No image data \n");
             return -1;
@@ -57,7 +35,7 @@ int main(int argc, char **argv) {
         ss.exec();
         return 0;
     }
-    cv::Mat ref = read_pnm(argv[argc - 1]);
+    cv::Mat ref = sift_io::imread(argv[argc - 1]);
     if (!ref.data) {
         printf("No image data \n");
         return -1;
@@ -67,7 +45,7 @@ int main(int argc, char **argv) {
     s_ref.exec();
     cv::Mat ref_descriptors = s_ref.get();
     for (int k = argc - 2; k >= 1; k--) {
-        cv::Mat img = read_pnm(argv[k]);
+        cv::Mat img = sift_io::imread(argv[k]);
         if (!img.data) {
             printf("No image data - %s \n", argv[k]);
             return -1;

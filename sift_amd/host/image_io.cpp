@@ -1,0 +1,183 @@
+#include "image_io.hpp"
+
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <vector>
+
+namespace sift_io {
+
+namespace {
+
+uint32_t be32(const unsigned char *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+cv::Mat fail(std::string *error, const char *why) {
+    if (error) *error = why;
+    return cv::Mat();
+}
+
+// PNG filter type 4 predictor
+int paeth(int a, int b, int c) {
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+cv::Mat read_pnm(const std::vector<unsigned char> &buf) {
+    // header: magic, width, height, maxval separated by whitespace, '#' comments allowed
+    std::size_t pos = 2;
+    auto number = [&]() -> long {
+        for (;;) {
+            while (pos < buf.size() && (buf[pos] == ' ' || buf[pos] == '\t' || buf[pos] == '\n' || buf[pos] == '\r')) pos++;
+            if (pos < buf.size() && buf[pos] == '#') {
+                while (pos < buf.size() && buf[pos] != '\n') pos++;
+                continue;
+            }
+            break;
+        }
+        long v = -1;
+        while (pos < buf.size() && buf[pos] >= '0' && buf[pos] <= '9') {
+            v = (v < 0 ? 0 : v) * 10 + (buf[pos] - '0');
+            pos++;
+        }
+        return v;
+    };
+    const bool colour = buf[1] == '6';
+    const long w = number(), h = number(), maxv = number();
+    pos++;  // the single whitespace byte after maxval
+    if (w <= 0 || h <= 0 || maxv != 255) return cv::Mat();
+    const std::size_t n = (std::size_t)w * h;
+    if (buf.size() < pos + n * (colour ? 3 : 1)) return cv::Mat();
+    cv::Mat m((int)h, (int)w, CV_8UC3);
+    const unsigned char *src = buf.data() + pos;
+    for (std::size_t i = 0; i < n; i++) {
+        if (colour) {  // file is RGB
+            m.data[3 * i] = src[3 * i + 2];
+            m.data[3 * i + 1] = src[3 * i + 1];
+            m.data[3 * i + 2] = src[3 * i];
+        } else {
+            m.data[3 * i] = m.data[3 * i + 1] = m.data[3 * i + 2] = src[i];
+        }
+    }
+    return m;
+}
+
+}  // namespace
+
+cv::Mat decode_png(const unsigned char *data, std::size_t size, std::string *error) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (size < 8 || std::memcmp(data, sig, 8) != 0) return fail(error, "not a PNG");
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<unsigned char> idat, palette;
+    std::size_t pos = 8;
+    bool seen_end = false;
+    while (pos + 12 <= size && !seen_end) {
+        const uint32_t len = be32(data + pos);
+        const unsigned char *type = data + pos + 4, *body = data + pos + 8;
+        if (pos + 12 + (std::size_t)len > size) return fail(error, "truncated chunk");
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) return fail(error, "bad IHDR");
+            w = be32(body);
+            h = be32(body + 4);
+            depth = body[8];
+            ctype = body[9];
+            interlace = body[12];
+        } else if (!std::memcmp(type, "PLTE", 4)) {
+            palette.assign(body, body + len);
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!std::memcmp(type, "IEND", 4)) {
+            seen_end = true;
+        }
+        pos += 12 + (std::size_t)len;
+    }
+    if (ctype < 0 || w == 0 || h == 0 || w > (1u << 20) || h > (1u << 20)) return fail(error, "bad header");
+    if (interlace) return fail(error, "interlaced PNG is not supported");
+    int channels;
+    switch (ctype) {
+        case 0: channels = 1; break;  // grey
+        case 2: channels = 3; break;  // RGB
+        case 3: channels = 1; break;  // palette index
+        case 4: channels = 2; break;  // grey + alpha
+        case 6: channels = 4; break;  // RGBA
+        default: return fail(error, "bad colour type");
+    }
+    const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                          (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                          ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+    if (!depth_ok) return fail(error, "bad bit depth");
+    if (ctype == 3 && palette.size() < 3) return fail(error, "missing palette");
+    const std::size_t bits_pp = (std::size_t)channels * depth;
+    const std::size_t stride = ((std::size_t)w * bits_pp + 7) / 8;  // bytes per scanline without the filter byte
+    const std::size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;         // filter distance in bytes
+    std::vector<unsigned char> raw((stride + 1) * (std::size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size())
+        return fail(error, "inflate failed");
+    // undo the scanline filters in place
+    std::vector<unsigned char> zero(stride, 0);
+    for (uint32_t y = 0; y < h; y++) {
+        unsigned char *line = raw.data() + (stride + 1) * y + 1;
+        const unsigned char *prev = y ? line - (stride + 1) : zero.data();
+        const int filter = line[-1];
+        for (std::size_t i = 0; i < stride; i++) {
+            const int a = i >= bpp ? line[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred;
+            switch (filter) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: pred = paeth(a, b, c); break;
+                default: return fail(error, "bad filter type");
+            }
+            line[i] = (unsigned char)(line[i] + pred);
+        }
+    }
+    cv::Mat m((int)h, (int)w, CV_8UC3);
+    const int maxv = (1 << depth) - 1;
+    for (uint32_t y = 0; y < h; y++) {
+        const unsigned char *line = raw.data() + (stride + 1) * y + 1;
+        unsigned char *dst = m.data + (std::size_t)y * w * 3;
+        for (uint32_t x = 0; x < w; x++) {
+            // sample k of pixel x as an 8-bit value (16-bit: high byte; sub-byte grey: scaled to 0..255)
+            auto sample = [&](int k) -> int {
+                if (depth == 8) return line[(std::size_t)x * channels + k];
+                if (depth == 16) return line[((std::size_t)x * channels + k) * 2];
+                const std::size_t bit = (std::size_t)x * depth;
+                return (line[bit >> 3] >> (8 - depth - (bit & 7))) & maxv;
+            };
+            int r, g, b;
+            if (ctype == 2 || ctype == 6) {
+                r = sample(0); g = sample(1); b = sample(2);
+            } else if (ctype == 3) {
+                const std::size_t idx = (std::size_t)sample(0) * 3;
+                if (idx + 2 >= palette.size()) return fail(error, "palette index out of range");
+                r = palette[idx]; g = palette[idx + 1]; b = palette[idx + 2];
+            } else {
+                int v = sample(0);
+                if (depth < 8) v = v * 255 / maxv;
+                r = g = b = v;
+            }
+            dst[3 * x] = (unsigned char)b;
+            dst[3 * x + 1] = (unsigned char)g;
+            dst[3 * x + 2] = (unsigned char)r;
+        }
+    }
+    return m;
+}
+
+cv::Mat imread(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return cv::Mat();
+    std::vector<unsigned char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (buf.size() >= 8 && buf[0] == 0x89 && buf[1] == 'P') return decode_png(buf.data(), buf.size());
+    if (buf.size() >= 7 && buf[0] == 'P' && (buf[1] == '5' || buf[1] == '6')) return read_pnm(buf);
+    return cv::Mat();
+}
+
+}  // namespace sift_io

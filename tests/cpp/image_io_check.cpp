@@ -1,0 +1,23 @@
+// Prints width, height, the BGR byte sum and an FNV-1a hash of the decoded pixels of each file given.
+#include <cstdint>
+#include <cstdio>
+
+#include "image_io.hpp"
+
+int main(int argc, char **argv) {
+    for (int k = 1; k < argc; k++) {
+        cv::Mat m = sift_io::imread(argv[k]);
+        if (!m.data) {
+            printf("%s EMPTY\n", argv[k]);
+            continue;
+        }
+        uint64_t sum = 0, hash = 1469598103934665603ull;
+        const size_t n = (size_t)m.rows * m.cols * 3;
+        for (size_t i = 0; i < n; i++) {
+            sum += m.data[i];
+            hash = (hash ^ m.data[i]) * 1099511628211ull;
+        }
+        printf("%s %d %d %llu %llu\n", argv[k], m.cols, m.rows, (unsigned long long)sum, (unsigned long long)hash);
+    }
+    return 0;
+}

@@ -58,12 +58,21 @@ def write_ppm(path, bgr):
 
 
 @pytest.mark.gpu
+def test_demo_reads_ppm_like_png(sift_lib, lenna_bgr, tmp_path):
+    build_host(sift_lib)
+    a = tmp_path / "Lenna.ppm"
+    write_ppm(a, lenna_bgr)
+    out = subprocess.run([os.path.join(HOST, "sift_demo"), str(a)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Keypoints Calculated: 1112" in out.stderr
+
+
+@pytest.mark.gpu
 def test_demo_matches_oracle(sift_lib, oracle, lenna_bgr, lenna_rotated_bgr, golden, tmp_path):
     """BASELINE config 1 through the C++ class: Lenna vs LennaRotated detect + describe + match."""
     build_host(sift_lib)
-    a, b = tmp_path / "LennaRotated.ppm", tmp_path / "Lenna.ppm"
-    write_ppm(a, lenna_rotated_bgr)
-    write_ppm(b, lenna_bgr)
+    # the reference's own invocation, ./smai res/LennaRotated.png res/Lenna.png (PNG files read by sift_io::imread)
+    a, b = os.path.join(ROOT, "tests", "golden", "LennaRotated.png"), os.path.join(ROOT, "tests", "golden", "Lenna.png")
     out = subprocess.run([os.path.join(HOST, "sift_demo"), str(a), str(b)], cwd=tmp_path, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr

@@ -1,0 +1,131 @@
+"""sift_amd/host/image_io: PNG / PNM files -> 8-bit BGR, the way cv::imread hands images to the
+reference's main.cpp:30.  Checked against PIL on the reference's own pictures and against
+hand-built PNGs of every colour type, bit depth and scanline filter."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HOST = os.path.join(ROOT, "sift_amd", "host")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("imgio") / "image_io_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-I" + HOST, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "image_io_check.cpp"), os.path.join(HOST, "image_io.cpp"),
+                           "-lz", "-o", exe])
+
+    def run(*paths):
+        out = subprocess.run([exe, *map(str, paths)], check=True, capture_output=True, text=True).stdout
+        return [line.split()[1:] for line in out.strip().splitlines()]
+    return run
+
+
+def fnv(bgr):
+    h = 1469598103934665603
+    for b in bgr.tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def expect(bgr):
+    return [str(bgr.shape[1]), str(bgr.shape[0]), str(int(bgr.sum(dtype=np.uint64))), str(fnv(bgr))]
+
+
+def chunk(tag, body):
+    return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+
+def paeth(a, b, c):
+    p = a + b - c
+    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+    return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+
+def make_png(w, h, ctype, depth, lines, filters, palette=None, idat_split=1):
+    """lines: h byte strings (unfiltered scanlines); filters: one filter type per line."""
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, channels * depth // 8)
+    raw = bytearray()
+    prev = bytes(len(lines[0]))
+    for line, ft in zip(lines, filters):
+        out = bytearray(len(line))
+        for i, v in enumerate(line):
+            a = line[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            pred = [0, a, b, (a + b) >> 1, paeth(a, b, c)][ft]
+            out[i] = (v - pred) & 255
+        raw.append(ft)
+        raw += out
+        prev = line
+    z = zlib.compress(bytes(raw), 6)
+    parts = [z[i * len(z) // idat_split:(i + 1) * len(z) // idat_split] for i in range(idat_split)]
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        png += chunk(b"PLTE", bytes(palette))
+    png += chunk(b"tEXt", b"Comment\x00ancillary chunks are skipped")
+    for p in parts:
+        png += chunk(b"IDAT", p)
+    return png + chunk(b"IEND", b"")
+
+
+def test_reference_pictures_decode_like_pil(checker, lenna_bgr, lenna_rotated_bgr, known):
+    got = checker(os.path.join(GOLDEN, "Lenna.png"), os.path.join(GOLDEN, "LennaRotated.png"))
+    assert got[0] == expect(lenna_bgr)
+    assert got[1] == expect(lenna_rotated_bgr)
+
+
+@pytest.mark.parametrize("ctype,depth", [(0, 8), (0, 16), (0, 4), (0, 2), (0, 1), (2, 8), (2, 16), (3, 8), (3, 4), (3, 1),
+                                         (4, 8), (4, 16), (6, 8), (6, 16)])
+def test_every_colour_type_depth_and_filter(checker, tmp_path, ctype, depth):
+    rng = np.random.default_rng(100 * ctype + depth)
+    w, h = 37, 23  # odd sizes: partial bytes at the end of sub-byte scanlines
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    palette = rng.integers(0, 256, size=3 * (1 << min(depth, 8)), dtype=np.uint8) if ctype == 3 else None
+    samples = rng.integers(0, 1 << depth, size=(h, w, channels), dtype=np.uint32)
+    lines = []
+    for y in range(h):
+        if depth == 8:
+            lines.append(samples[y].astype(np.uint8).tobytes())
+        elif depth == 16:
+            lines.append(samples[y].astype(">u2").tobytes())
+        else:
+            bits = np.zeros((w * depth + 7) // 8 * 8, np.uint8)
+            vals = samples[y, :, 0]
+            for k in range(depth):
+                bits[np.arange(w) * depth + k] = (vals >> (depth - 1 - k)) & 1
+            lines.append(np.packbits(bits).tobytes())
+    filters = [(y + ctype) % 5 for y in range(h)]
+    path = tmp_path / ("t_%d_%d.png" % (ctype, depth))
+    path.write_bytes(make_png(w, h, ctype, depth, lines, filters, palette, idat_split=3))
+    s8 = samples >> 8 if depth == 16 else samples
+    if ctype in (2, 6):
+        rgb = s8[:, :, :3]
+    elif ctype == 3:
+        rgb = palette.reshape(-1, 3)[samples[:, :, 0]]
+    else:
+        g = s8[:, :, 0] if depth >= 8 else samples[:, :, 0] * 255 // ((1 << depth) - 1)
+        rgb = np.stack([g, g, g], axis=2)
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1]).astype(np.uint8)
+    assert checker(path)[0] == expect(bgr)
+
+
+def test_pnm_and_unreadable_files(checker, tmp_path):
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, size=(9, 14, 3), dtype=np.uint8)
+    gray = rng.integers(0, 256, size=(9, 14), dtype=np.uint8)
+    (tmp_path / "c.ppm").write_bytes(b"P6\n# a comment\n14 9\n255\n" + rgb.tobytes())
+    (tmp_path / "g.pgm").write_bytes(b"P5 14 9 255\n" + gray.tobytes())
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"garbage" * 10)
+    (tmp_path / "short.ppm").write_bytes(b"P6 14 9 255\n" + rgb.tobytes()[:50])
+    got = checker(tmp_path / "c.ppm", tmp_path / "g.pgm", tmp_path / "bad.png", tmp_path / "short.ppm", tmp_path / "missing.png")
+    assert got[0] == expect(np.ascontiguousarray(rgb[:, :, ::-1]))
+    assert got[1] == expect(np.stack([gray] * 3, axis=2))
+    assert got[2] == ["EMPTY"] and got[3] == ["EMPTY"] and got[4] == ["EMPTY"]
