@@ -180,12 +180,15 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                 for (int m = 0; m < CY; m++) {
                     const int y = y0 + m;
                     if (y >= ys && y < ye) {
-                        const size_t o = (size_t)y * w + gx;
-                        out[o] = acc[m];
-                        if (dog) dog[o] = acc[m] - centre[m];
-                        if (nxt && !((gx | y) & 1)) {
-                            const int hx = gx >> 1, hy = y >> 1;
-                            if (hx < nw && hy < nh) nxt[(size_t)hy * nw + hx] = acc[m];
+                        // the row is wave-uniform: scalar row pointers, one vector offset
+                        const size_t orow = (size_t)y * w;
+                        const unsigned xoff = (unsigned)gx * 8u;  // byte offset inside the row
+                        *reinterpret_cast<double *>(reinterpret_cast<char *>(out + orow) + xoff) = acc[m];
+                        if (dog) *reinterpret_cast<double *>(reinterpret_cast<char *>(dog + orow) + xoff) = acc[m] - centre[m];
+                        if (nxt && !(y & 1) && (y >> 1) < nh) {
+                            const int hx = gx >> 1;
+                            if (!(gx & 1) && hx < nw)
+                                *reinterpret_cast<double *>(reinterpret_cast<char *>(nxt + (size_t)(y >> 1) * nw) + xoff / 2) = acc[m];
                         }
                     }
                 }
