@@ -4,9 +4,10 @@
 // Replaces scale_space_extrema_parallel::operator() and its helpers
 // (sift.cpp:227-448).  Floating-point operations are written in the order of a
 // scalar evaluation of those functions and contraction is off for this file,
-// so localisation is bit-reproducible against a CPU evaluation; the
-// orientation histogram is summed per lane and combined in a fixed tree order,
-// so it is deterministic run to run.
+// so localisation is bit-reproducible against a CPU evaluation; each partial
+// orientation histogram is updated by lanes of a single wave only and the
+// partial histograms are combined in a fixed order, so it is reproducible run
+// to run.
 #include "common.h"
 #include "kernels.h"
 
