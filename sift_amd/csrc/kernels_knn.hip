@@ -121,10 +121,14 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
         qnorm[qb] = nrm;
     }
 
-    int b1[QB], b2[QB], i1[QB], i2[QB];
+    // Each query is scanned by two lanes (lane and lane ^ 32), each over half of the rows of a
+    // block with its own running top-2 (b1 <= b2).  thr is the second smallest of the four
+    // values the pair holds: a row at or above it cannot be in the query's final top-2 (an
+    // equal distance loses to the smaller index already held), so it gates the update path.
+    int b1[QB], b2[QB], i1[QB], i2[QB], thr[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
-        b1[qb] = b2[qb] = INT_MAX;
+        b1[qb] = b2[qb] = thr[qb] = INT_MAX;
         i1[qb] = i2[qb] = -1;
     }
 
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
             bool any_hit = false;
 #pragma unroll
             for (int qb = 0; qb < QB; qb++) {
-                hit[qb] = min16(acc[qb]) < b2[qb];
+                hit[qb] = min16(acc[qb]) < thr[qb];
                 any_hit |= hit[qb];
             }
             if (__any(any_hit)) {
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
                         for (int r = 0; r < 16; r++) {
                             const int sv = acc[qb][r];
                             // most rows lose against the running second-best in every lane: skip them whole
-                            if (__any(sv < b2[qb])) {
+                            if (__any(sv < thr[qb])) {
                                 const int idx = idx0 + (r & 3) + 8 * (r >> 2);
                                 if (sv < b1[qb]) {
                                     b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = sv; i1[qb] = idx;
@@ -220,6 +224,8 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
                                 }
                             }
                         }
+                        const int p1 = __shfl_xor(b1[qb], 32), p2 = __shfl_xor(b2[qb], 32);
+                        thr[qb] = min(max(b1[qb], p1), min(b2[qb], p2));
                     }
                 }
             }
