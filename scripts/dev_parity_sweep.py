@@ -6,7 +6,12 @@ import sift_amd as S
 from oracle import oracle as O
 ctx = S.Context(0)
 tot = dict(kp=0, angle=0, desc_rows=0, frames=0, count_mismatch=0)
-for (w, h, seed, nf) in [(1920, 1080, 1, 6), (960, 540, 1, 6), (640, 480, 9, 8)]:
+import os
+BIG = os.environ.get('SWEEP') == 'big'
+CASES = [(1920, 1080, 1, 6), (960, 540, 1, 6), (640, 480, 9, 8)]
+if BIG:
+    CASES = [(1920, 1080, 3, 24), (1280, 720, 4, 24), (640, 480, 5, 40), (1001, 703, 6, 12), (3840, 2160, 7, 2), (333, 517, 8, 20)]
+for (w, h, seed, nf) in CASES:
     for f in range(nf):
         img = S.synth_dead_leaves(seed, f, w, h)
         o = O.OracleSift(img).exec(threads=16, blur_threads=16)
