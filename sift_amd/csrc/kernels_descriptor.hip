@@ -177,6 +177,8 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                         const double bin_col = sv * dj + Bv[r];
                         if (!(bin_row > -1 && bin_col > -1 && bin_row < WINDOW_WIDTH && bin_col < WINDOW_WIDTH)) continue;
                         // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) (sift.cpp:512-517) as a product of two table entries
+                        // a zero gradient adds +0.0 to eight bins, which leaves every one of them unchanged
+                        if (g[r].mag == 0.0) continue;
                         const double wcol = use_tab ? wj[r] : exp(wscale * (double)(j * j));
                         const double magnitude = g[r].mag * (wi[r] * wcol);                  // sift.cpp:518
                         const double orientation = g[r].ori * bins_per_degree - ang_bins;  // sift.cpp:519
