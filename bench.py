@@ -86,10 +86,14 @@ def main():
     # ---- synthetic frames, resident in HBM before the timed region -----------
     npool = max(1, args.pool)
     host = np.empty((npool * B, H, W), np.uint8)
-    for p in range(npool):
-        for i in range(B):
-            gidx = (p * world + rank) * B + i
-            host[p * B + i] = S.synth_dead_leaves(1, gidx, W, H)
+
+    def make_frame(k):
+        p, i = divmod(k, B)
+        host[k] = S.synth_dead_leaves(1, (p * world + rank) * B + i, W, H)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 1) // max(1, world)))) as ex:
+        list(ex.map(make_frame, range(npool * B)))  # the generator is a reentrant C function (GIL released)
     pool = torch.from_numpy(host).cuda()
     torch.cuda.synchronize()
 
