@@ -144,12 +144,23 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
 #pragma unroll
             for (int m = 0; m < CX; m++) q[m] = acc[m];
         }
+        // column pass: lane <-> column, consecutive output rows per thread.  A wave is one
+        // 64-column row group: its ring slots, centre rows and output rows are scalars.
+        const int x = tid & (TW - 1), cy = __builtin_amdgcn_readfirstlane(tid / TW);
+        const int rel0 = MCH * s + cy * CY - R;  // strip-relative index of the first output row
+        // Un-filtered centres of this thread's output rows: strip-relative row rel was staged in
+        // step rel / MCH, i.e. in this step's buffer or in the other one.  They are read BEFORE the
+        // barrier: after it, a wave that is done with its column pass starts the next step and
+        // overwrites the other buffer.
+        double centre[CY];
+#pragma unroll
+        for (int m = 0; m < CY; m++) {
+            const int rel = rel0 + m;
+            centre[m] = (dog && rel >= 0) ? smem[((rel / MCH) & 1) * (MCH * G::PIN) + (rel % MCH) * G::PIN + x + R] : 0.0;
+        }
         __syncthreads();
-        {   // column pass: lane <-> column, 8 consecutive output rows per thread
-            // a wave is one 64-column row group: its ring slots, centre rows and output rows are scalars
-            const int x = tid & (TW - 1), cy = __builtin_amdgcn_readfirstlane(tid / TW);
-            const int rel0 = MCH * s + cy * CY - R;  // strip-relative index of the first output row
-            const int y0 = ys - R + rel0;            // its image row
+        {
+            const int y0 = ys - R + rel0;  // image row of the first output row
             const int gx = tx0 + x;
             if (y0 + CY > ys && y0 < ye && gx < w) {
                 double v[CY + 2 * R];
@@ -158,15 +169,6 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                 for (int k = 0; k < CY + 2 * R; k++) {
                     v[k] = ring[slot * G::PR + x];
                     slot = slot + 1 == G::RING ? 0 : slot + 1;
-                }
-                // un-filtered centres: strip-relative row rel was staged in step rel / 32
-                double centre[CY];
-#pragma unroll
-                for (int m = 0; m < CY; m++) {
-                    const int rel = rel0 + m;
-                    centre[m] = (dog && rel >= 0)
-                                    ? smem[((rel / MCH) & 1) * (MCH * G::PIN) + (rel % MCH) * G::PIN + x + R]
-                                    : 0.0;
                 }
                 double acc[CY];
 #pragma unroll
