@@ -7,11 +7,11 @@
 // sift.cpp:173) and, for level 3, the nearest-neighbour half-size base of the
 // next octave (sift.cpp:152-153) in the same pass.
 //
-// Marching structure: a workgroup owns a 64-column strip and walks down it 32
-// rows at a time.  Each step stages 32 new input rows (plus the horizontal
-// halo) in one of two LDS buffers, row-filters them into a ring of
-// row-filtered rows (also LDS) and then column-filters the 32 output rows
-// whose 2R+1 supports are now complete.  Every input row is read from HBM and
+// Marching structure: a workgroup owns a strip of 128 (or 64) columns and walks
+// down it 16 (or 32) rows at a time.  Each step stages the new input rows (plus
+// the horizontal halo) in one of two LDS buffers, row-filters them into a ring
+// of row-filtered rows (also LDS) and then column-filters the output rows whose
+// 2R+1 supports are now complete.  Every input row is read from HBM and
 // row-filtered once per strip (no vertical halo recompute); the un-filtered
 // centre values the DoG needs come from the two staging buffers, not from a
 // second global read; the next step's input is prefetched into registers while
@@ -30,14 +30,17 @@ namespace sa {
 
 namespace {
 
-constexpr int TW = 64;   // strip width (outputs)
-constexpr int MCH = 32;  // rows per step
+// Strip geometry.  Filters up to 21 taps use 128-column strips walked 16 rows at a time
+// (1 KB contiguous per row: fewer, longer bursts and half the column halo); the 27-tap filter
+// would then need 83 KB of LDS and fit one workgroup per CU, so it keeps 64 columns x 32 rows.
 
 // Threads per workgroup: 256 (8 consecutive outputs per thread in either pass) for the short
 // filters, 512 (4 outputs per thread, half the registers, twice the waves per SIMD) for the
 // long ones, whose loops are bound by fp64 issue and need the extra waves to stay busy.
 template <int R>
 struct MarchGeom {
+    static constexpr int TW = R <= 10 ? 128 : 64;   // strip width (outputs)
+    static constexpr int MCH = R <= 10 ? 16 : 32;   // rows per step
     static constexpr int NTHREADS = 512;
     static constexpr int CX = TW / (NTHREADS / MCH);   // consecutive outputs per thread in the row pass
     static constexpr int CY = MCH / (NTHREADS / TW);   // consecutive outputs per thread in the column pass
@@ -85,7 +88,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                                       double *__restrict__ nxt, int w, int h, int nw, int nh, int strip_h,
                                       const Taps &taps, double *smem, const TileId tile) {
     using G = MarchGeom<R>;
-    constexpr int NTHREADS = G::NTHREADS, CX = G::CX, CY = G::CY;
+    constexpr int NTHREADS = G::NTHREADS, CX = G::CX, CY = G::CY, TW = G::TW, MCH = G::MCH;
     static_assert(R < MCH, "the centre rows of one step lie in the last two staging buffers");
     double *ring = smem + 2 * MCH * G::PIN;
     const int tid = threadIdx.x;
@@ -144,8 +147,8 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
 #pragma unroll
             for (int m = 0; m < CX; m++) q[m] = acc[m];
         }
-        // column pass: lane <-> column, consecutive output rows per thread.  A wave is one
-        // 64-column row group: its ring slots, centre rows and output rows are scalars.
+        // column pass: lane <-> column, consecutive output rows per thread.  A wave lies in one
+        // row group: its ring slots, centre rows and output rows are scalars.
         const int x = tid & (TW - 1), cy = __builtin_amdgcn_readfirstlane(tid / TW);
         const int rel0 = MCH * s + cy * CY - R;  // strip-relative index of the first output row
         // Un-filtered centres of this thread's output rows: strip-relative row rel was staged in
@@ -226,11 +229,13 @@ __global__ __launch_bounds__(MarchGeom<R>::NTHREADS) void k_base_march(const uin
     march<R>(source, out + f * out_frame_stride, nullptr, nullptr, 2 * W, 2 * H, 0, 0, strip_h, taps, smem, tile);
 }
 
-// strips of 64 columns, cut vertically so that the launch has >= ~2048 workgroups
+// strips cut vertically so that the launch has >= ~2048 workgroups
+template <int R>
 void strip_grid(int w, int h, int nframes, dim3 &grid, int &strip_h) {
+    constexpr int TW = MarchGeom<R>::TW, MCH = MarchGeom<R>::MCH;
     const int nx = (w + TW - 1) / TW;
     int ny = (2048 + nx * nframes - 1) / (nx * nframes);
-    const int max_ny = (h + 4 * MCH - 1) / (4 * MCH);  // at least 128 rows per strip
+    const int max_ny = (h + 127) / 128;  // at least 128 rows per strip
     if (ny > max_ny) ny = max_ny;
     if (ny < 1) ny = 1;
     strip_h = (h + ny - 1) / ny;
@@ -257,7 +262,7 @@ void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nfram
     }
     dim3 grid;
     int strip_h;
-    strip_grid(w, h, nframes, grid, strip_h);
+    strip_grid<R>(w, h, nframes, grid, strip_h);
     hipLaunchKernelGGL(k_blur_march<R>, grid, dim3(MarchGeom<R>::NTHREADS), MarchGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h,
                        nw, nh, (size_t)IMAGES * plane, (size_t)NDOG * plane, next_stride, strip_h, taps);
 }
@@ -310,7 +315,7 @@ void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframe
     const int w = 2 * W, h = 2 * H;
     dim3 grid;
     int strip_h;
-    strip_grid(w, h, nframes, grid, strip_h);
+    strip_grid<5>(w, h, nframes, grid, strip_h);
     hipLaunchKernelGGL(k_base_march<5>, grid, dim3(MarchGeom<5>::NTHREADS), MarchGeom<5>::LDS_BYTES, st, frames, W, H, p.gauss[0],
                        (size_t)IMAGES * w * h, strip_h, taps);
 }
