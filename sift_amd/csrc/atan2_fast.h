@@ -78,4 +78,19 @@ SA_HD double div_pi(double a) {
     return fma(fma(-q, 3.14159265358979323846, a), SA_INV_PI, q);
 }
 
+// a / 360 with the IEEE quotient's rounding, for |a| up to a few thousand: same
+// reciprocal-multiply-and-correct scheme as div_pi.
+SA_HD double div_360(double a) {
+    const double inv = 1.0 / 360.0;
+    const double q = a * inv;
+    return fma(fma(-q, 360.0, a), inv, q);
+}
+
+// round() for |v| < 2^31: to nearest, halves away from zero.
+SA_HD int round_half_away(double v) {
+    double t = trunc(v);
+    if (fabs(v - t) >= 0.5) t += copysign(1.0, v);  // v - t is exact
+    return (int)t;
+}
+
 }  // namespace sa

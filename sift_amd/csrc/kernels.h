@@ -21,7 +21,7 @@ void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Cand
                     FrameCounters *counters);
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
                             DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
-                            int32_t *n_localized, int32_t *cursors);
+                            int32_t *n_localized);
 
 // kernels_keypoints.hip
 void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevKeypoint *sorted, DevKeypoint *final_kp,

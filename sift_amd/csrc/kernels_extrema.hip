@@ -9,6 +9,7 @@
 // partial histograms are combined in a fixed order, so it is reproducible run
 // to run.
 #include "common.h"
+#include "atan2_fast.h"
 #include "kernels.h"
 
 namespace sa {
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void k_localize(Pyramid p, const Candidate *__
 }
 
 // get_keypoint_orientations (sift.cpp:393-448), one wave per localised
-// keypoint; waves pull keypoints from a per-frame cursor.
+// keypoint; keypoints are dealt round-robin to the waves of their frame.
 //
 // The 36-bin histogram is kept as 16 partial histograms in LDS, one per
 // lane & 15, updated with LDS double atomics; a partial histogram is only ever
@@ -306,8 +307,7 @@ constexpr int WTAB = 128;
 __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeypoint *__restrict__ localized,
                                                          int kp_cap, DevKeypoint *__restrict__ oriented,
                                                          FrameCounters *__restrict__ counters,
-                                                         const int32_t *__restrict__ n_localized,
-                                                         int32_t *__restrict__ cursors) {
+                                                         const int32_t *__restrict__ n_localized) {
     __shared__ double s_hist[OWAVES][BINS * OSTRIDE];
     __shared__ double s_hsum[OWAVES][BINS];
     __shared__ double s_smooth[OWAVES][BINS];
@@ -317,11 +317,10 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
     double *hist = s_hist[wv], *hsum = s_hsum[wv], *smooth = s_smooth[wv], *wtab = s_wtab[wv];
     int n = n_localized[f];
     if (n > kp_cap) n = kp_cap;
-    for (;;) {
-        int idx = 0;
-        if (lane == 0) idx = atomicAdd(&cursors[f], 1);
-        idx = __shfl(idx, 0);
-        if (idx >= n) break;
+    // keypoints are dealt to the waves of the frame round-robin: a shared cursor would cost one
+    // same-address global atomic per keypoint, which serialises the whole frame
+    const int wave_in_frame = blockIdx.x * OWAVES + wv, waves_per_frame = gridDim.x * OWAVES;
+    for (int idx = wave_in_frame; idx < n; idx += waves_per_frame) {
         const DevKeypoint kpt = localized[(size_t)f * kp_cap + idx];
         const int layer = kpt.pad & 255, oct = kpt.pad >> 8;
         const int w = p.w[oct], h = p.h[oct];
@@ -340,8 +339,11 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int n1 = 2 * radius + 1;
         const int total = n1 * n1;
-        const float inv_n1 = 1.0f / (float)n1;
         const int copy = lane & (OCOPIES - 1);
+        // The (2 radius + 1)^2 window is walked in row-major order, sample s = lane, lane + 64, ...
+        // (row, column) of a lane's sample advance by 64 samples at a time: no division in the loop.
+        const int q64 = 64 / n1, r64 = 64 - q64 * n1;
+        int qi = lane / n1, rj = lane - qi * n1;
         // Four samples per lane per trip.  Gradient loads are unconditional (addresses clamped
         // into the plane) and the weight-table reads come before the first atomic, so all of a
         // trip's reads are in flight together; samples outside the image are discarded.
@@ -351,24 +353,27 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int s = s0 + 64 * u;
-                int qi = (int)((float)s * inv_n1);
-                int rj = s - qi * n1;
-                if (rj < 0) { qi--; rj += n1; }
-                if (rj >= n1) { qi++; rj -= n1; }
                 const int ii = qi - radius, jj = rj - radius;
                 const int y = base_y + ii, x = base_x + jj;
-                ok[u] = s < total && y > 0 && y < h - 1 && x > 0 && x < w - 1;  // sift.cpp:407,409
+                ok[u] = s0 + 64 * u < total && y > 0 && y < h - 1 && x > 0 && x < w - 1;  // sift.cpp:407,409
                 const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
                 g[u] = L[(size_t)yc * w + xc];  // mag, direction (sift.cpp:410-415)
                 wgt[u] = use_tab ? wtab[min(abs(ii), WTAB - 1)] * wtab[min(abs(jj), WTAB - 1)]
                                  : exp(weight_factor * (ii * ii + jj * jj));
+                rj += r64;
+                qi += q64;
+                if (rj >= n1) {
+                    rj -= n1;
+                    qi++;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (!ok[u]) continue;
-                const int index = ((int)round((g[u].ori * BINS) / 360) % BINS + BINS) % BINS;  // sift.cpp:416
-                atomicAdd(&hist[index * OSTRIDE + copy], wgt[u] * g[u].mag);                  // sift.cpp:417
+                // ((int)round(ori*36/360) % 36 + 36) % 36 (sift.cpp:416); |ori| <= 180, so the rounded value lies in [-18, 18]
+                const int k = round_half_away(div_360(g[u].ori * BINS));
+                const int index = k < 0 ? k + BINS : k;
+                atomicAdd(&hist[index * OSTRIDE + copy], wgt[u] * g[u].mag);  // sift.cpp:417
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -435,11 +440,11 @@ void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Cand
 
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
                             DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
-                            int32_t *n_localized, int32_t *cursors) {
+                            int32_t *n_localized) {
     hipLaunchKernelGGL(k_localize, dim3((cand_cap + 255) / 256, nframes), dim3(256), 0, st, p, cand, cand_cap,
                        localized, kp_cap, counters, n_localized);
     hipLaunchKernelGGL(k_orient, dim3(1024 / OWAVES, nframes), dim3(64 * OWAVES), 0, st, p, localized, kp_cap,
-                       oriented, counters, n_localized, cursors);
+                       oriented, counters, n_localized);
 }
 
 }  // namespace sa

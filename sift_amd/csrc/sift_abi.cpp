@@ -90,7 +90,7 @@ struct sift_batch {
     int kp_cap = 0;
     uint8_t *d_desc = nullptr;
     FrameCounters *d_counters = nullptr;
-    int32_t *d_cursors = nullptr;  // [3][max_frames]: orientation cursor, descriptor cursor, localised count
+    int32_t *d_cursors = nullptr;  // [3][max_frames]: (unused), descriptor cursor, localised count
     Taps base_taps{};
     int base_ntaps = 0;
     Taps lvl_taps[IMAGES]{};
@@ -364,8 +364,7 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
     for (int o = 0; o < b->pyr.octaves; o++)
         TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
     TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_sorted, b->d_oriented,
-                                                      b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames,
-                                                      b->d_cursors));
+                                                      b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames));
     TIMED(SIFT_STAGE_CLEAN,
           launch_clean(st, n, b->d_oriented, b->d_sorted, b->d_final, b->d_flags, b->kp_cap, b->d_counters));
     TIMED(SIFT_STAGE_DESCRIPTOR, launch_descriptors(st, b->pyr, n, b->d_final, b->kp_cap, b->d_counters,

@@ -58,6 +58,24 @@ int main() {
             check(t, 1.0); check(1.0, t); check(-t, -1.0); check(1.0, -t);
         }
     check(0.0, 0.0); check(0.0, -1.0); check(1e-300, 1e-300); check(3e-310, 1e-305);
+    // the orientation-bin quotient (ori*36)/360 (sift.cpp:416) and round(): exact agreement required
+    long bin_bad = 0;
+    auto check_bin = [&](double ori) {
+        const double a = ori * 36, want = a / 360, got = sa::div_360(a);
+        if (got != want || sa::round_half_away(got) != (int)round(want)) bin_bad++;
+    };
+    for (int k = 0; k < 4000000; k++) check_bin((uni() * 2 - 1) * 180.0);
+    for (int m = -18; m <= 18; m++)
+        for (int k = -2000; k <= 2000; k++) {
+            check_bin(nextafter(5.0 + 10.0 * m, 1e9) + k * 1e-13);
+            double v = 5.0 + 10.0 * m;
+            for (int q = 0; q < (k < 0 ? -k : k) % 40; q++) v = nextafter(v, k < 0 ? -1e9 : 1e9);
+            check_bin(v);
+        }
+    const double halves[] = {0.5, -0.5, 0.49999999999999994, -0.49999999999999994, 1.5, 2.5, -17.5, 17.5, 0.0, -0.0};
+    for (double hv : halves)
+        if (sa::round_half_away(hv) != (int)round(hv)) bin_bad++;
+    printf("bin_mismatches %ld\n", bin_bad);
     printf("samples %ld max_ulp %.3f not_identical %ld max_ulp_deg %.3f not_identical_deg %ld\n", n, worst, diff, worst_deg,
            diff_deg);
     return 0;

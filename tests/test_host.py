@@ -154,6 +154,7 @@ def test_fast_atan2_is_within_two_ulps_of_libm(tmp_path):
                     os.path.join(root, "tests", "cpp", "atan2_check.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "div_pi mismatch" not in out
+    assert "bin_mismatches 0" in out  # div_360 and round_half_away reproduce (ori*36)/360 and round() (sift.cpp:416)
     m = re.search(r"samples (\d+) max_ulp ([\d.]+) not_identical (\d+) max_ulp_deg ([\d.]+)", out)
     assert m, out
     assert int(m.group(1)) > 4_000_000
