@@ -54,6 +54,7 @@ struct MarchGeom {
 
 // Source of the blur levels: the previous Gaussian level.
 struct LevelSource {
+    static constexpr bool kQuads = false;
     const double *in;
     int w;
     __device__ __forceinline__ double operator()(int gy, int gx) const { return in[(size_t)gy * w + gx]; }
@@ -64,9 +65,37 @@ struct LevelSource {
 // coordinate (d+0.5)/2-0.5 clamped at the edges, i.e. even d = 2k takes
 // 0.25*s[k-1] + 0.75*s[k] and odd d = 2k+1 takes 0.75*s[k] + 0.25*s[k+1];
 // 8-bit inputs make every product and sum exact in double.
+//
+// The staging tile of the base blur starts at an odd row and an odd column, so it
+// splits into 2x2 output quads (rows 2j+1, 2j+2; columns 2k+1, 2k+2) that all
+// interpolate between the same four source pixels a = s[j][k], b = s[j][k+1],
+// c = s[j+1][k], d = s[j+1][k+1]: (9a+3b+3c+d)/16 and its three mirror images,
+// exact in integers.  `load_quad` only loads (so that the loads of the next step
+// stay in flight during this step's filter), `blend` does the arithmetic; quads
+// that touch or cross the frame border are recomputed pixel by pixel.
 struct UpsampleSource {
+    static constexpr bool kQuads = true;
     const uint8_t *src;
     int W, H;
+    __device__ __forceinline__ void load_quad(int gy, int gx, int raw[4]) const {
+        const int j = (gy - 1) >> 1, k = (gx - 1) >> 1;
+        const int j0 = min(max(j, 0), H - 1), j1 = min(max(j + 1, 0), H - 1);
+        const int k0 = min(max(k, 0), W - 1), k1 = min(max(k + 1, 0), W - 1);
+        raw[0] = src[(unsigned)(j0 * W + k0)];
+        raw[1] = src[(unsigned)(j0 * W + k1)];
+        raw[2] = src[(unsigned)(j1 * W + k0)];
+        raw[3] = src[(unsigned)(j1 * W + k1)];
+    }
+    __device__ __forceinline__ bool interior(int gy, int gx) const {
+        return gy >= 1 && gy + 1 < 2 * H && gx >= 1 && gx + 1 < 2 * W;
+    }
+    static __device__ __forceinline__ void blend(const int raw[4], double o[4]) {
+        const int a = raw[0], b = raw[1], c = raw[2], d = raw[3];
+        o[0] = (double)(9 * a + 3 * b + 3 * c + d) * 0.0625;
+        o[1] = (double)(3 * a + 9 * b + c + 3 * d) * 0.0625;
+        o[2] = (double)(3 * a + b + 9 * c + 3 * d) * 0.0625;
+        o[3] = (double)(a + 3 * b + 3 * c + 9 * d) * 0.0625;
+    }
     __device__ __forceinline__ double operator()(int gy, int gx) const {
         int sx = (gx - 1) >> 1, sy = (gy - 1) >> 1;  // floor((d-1)/2)
         double fx = (gx & 1) ? 0.25 : 0.75, fy = (gy & 1) ? 0.25 : 0.75;
@@ -97,35 +126,75 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
     const int ye = min(h, ys + strip_h);
     const int nsteps = (ye - ys + 2 * R + MCH - 1) / MCH;
 
-    // this thread's share of a 32 x COLS staging tile: fixed (row, column) per slot
-    int pf_row[G::NLOAD], pf_gx[G::NLOAD], pf_lds[G::NLOAD];
+    // This thread's share of a MCH x COLS staging tile: fixed (row, column) per slot.  `fetch`
+    // issues the loads of step s into registers, `stage` writes them to the step's LDS buffer.
+    constexpr bool kQuads = Source::kQuads;
+    constexpr int QC = G::COLS / 2, NQUAD = (MCH / 2) * QC;
+    constexpr int NSLOT = kQuads ? (NQUAD + NTHREADS - 1) / NTHREADS : G::NLOAD;
+    static_assert(!kQuads || ((R & 1) && !(MCH & 1) && !(TW & 1)), "quads need an odd tile origin and even tile sides");
+    int pf_row[NSLOT], pf_gx[NSLOT], pf_lds[NSLOT];
+    double pf[kQuads ? 1 : NSLOT];
+    int raw[kQuads ? NSLOT : 1][4];
 #pragma unroll
-    for (int u = 0; u < G::NLOAD; u++) {
+    for (int u = 0; u < NSLOT; u++) {
         const int idx = tid + NTHREADS * u;
-        const int r = idx / G::COLS, c = idx % G::COLS;
-        pf_row[u] = idx < MCH * G::COLS ? r : -1;
-        pf_gx[u] = reflect101(tx0 - R + c, w);
-        pf_lds[u] = r * G::PIN + c;
+        if constexpr (kQuads) {
+            const int r = 2 * (idx / QC), c = 2 * (idx % QC);
+            pf_row[u] = idx < NQUAD ? r : -1;
+            pf_gx[u] = tx0 - R + c;  // not reflected: border quads are recomputed
+            pf_lds[u] = r * G::PIN + c;
+        } else {
+            const int r = idx / G::COLS, c = idx % G::COLS;
+            pf_row[u] = idx < MCH * G::COLS ? r : -1;
+            pf_gx[u] = reflect101(tx0 - R + c, w);
+            pf_lds[u] = r * G::PIN + c;
+        }
     }
-    double pf[G::NLOAD];
     auto fetch = [&](int s) {
         const int v0 = ys - R + MCH * s;
 #pragma unroll
-        for (int u = 0; u < G::NLOAD; u++) {
-            if (pf_row[u] >= 0) {
-                int gy = v0 + pf_row[u];
-                if ((unsigned)gy >= (unsigned)h) gy = reflect101(gy, h);  // only the strips at the image edge
-                pf[u] = source(gy, pf_gx[u]);
+        for (int u = 0; u < NSLOT; u++) {
+            if constexpr (kQuads) {
+                if ((u + 1) * NTHREADS <= NQUAD || pf_row[u] >= 0) source.load_quad(v0 + pf_row[u], pf_gx[u], raw[u]);
+            } else {
+                if (pf_row[u] >= 0) {
+                    int gy = v0 + pf_row[u];
+                    if ((unsigned)gy >= (unsigned)h) gy = reflect101(gy, h);  // only the strips at the image edge
+                    pf[u] = source(gy, pf_gx[u]);
+                }
             }
         }
+    };
+    auto stage = [&](int s, double *s_in) {
+        const int v0 = ys - R + MCH * s;
+#pragma unroll
+        for (int u = 0; u < NSLOT; u++) {
+            if (pf_row[u] < 0) continue;
+            if constexpr (kQuads) {
+                const int gy = v0 + pf_row[u], gx = pf_gx[u];
+                double o[4];
+                if (source.interior(gy, gx)) {
+                    Source::blend(raw[u], o);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[i] = source(reflect101(gy + (i >> 1), h), reflect101(gx + (i & 1), w));
+                }
+                double *q = s_in + pf_lds[u];
+                q[0] = o[0];
+                q[1] = o[1];
+                q[G::PIN] = o[2];
+                q[G::PIN + 1] = o[3];
+            } else {
+                s_in[pf_lds[u]] = pf[u];
+            }
+        }
+        (void)v0;
     };
 
     fetch(0);
     for (int s = 0; s < nsteps; s++) {
         double *s_in = smem + (s & 1) * (MCH * G::PIN);
-#pragma unroll
-        for (int u = 0; u < G::NLOAD; u++)
-            if (pf_row[u] >= 0) s_in[pf_lds[u]] = pf[u];
+        stage(s, s_in);
         __syncthreads();  // staging tile complete; previous step's column pass is done with the ring
         if (s + 1 < nsteps) fetch(s + 1);
         {   // row pass: lane <-> row, 8 consecutive outputs per thread
