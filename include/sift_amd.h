@@ -185,6 +185,27 @@ int sift_knn2_merge_device(sift_ctx *ctx, const void *d_parts, int nparts, int n
  * of good matches through *n_good and their query indices in good_idx. */
 int sift_match_min_dist_filter(const sift_knn2 *knn, int nq, int32_t *good_idx, int32_t *n_good);
 
+/* ---- homography from matches ------------------------------------------------ */
+/* Replaces cv::findHomography(obj, scene, RANSAC, 3, mask) at main.cpp:105 (OpenCV
+ * calib3d: RANSAC over 4-point normalised-DLT models with cv::RNG((uint64)-1),
+ * a least-squares fit over the inliers, 10 Levenberg-Marquardt iterations).
+ * The 4-point models and their inlier counts are evaluated on the GPU for a
+ * whole chunk of iterations at once; the outcome is the sequential loop's. */
+typedef struct sift_homography_info {
+    int32_t found;             /* 0: no model (fewer than 4 points, or no usable subset); H is all zeros */
+    int32_t iterations;        /* RANSAC iterations the sequential loop would have executed */
+    int32_t best_iteration;    /* the iteration whose model was kept */
+    int32_t inliers;           /* non-zeros of mask */
+    int32_t lm_iterations;     /* Levenberg-Marquardt iterations of the final polish */
+    int32_t hypotheses_scored; /* 4-point models evaluated on the GPU (>= iterations) */
+} sift_homography_info;
+/* src_xy, dst_xy: n interleaved (x, y) float pairs on the host (the Point2f vectors
+ * of main.cpp:92-101).  H: 3x3 row-major, maps src to dst.  mask (may be NULL): n
+ * bytes, 1 for inliers.  OpenCV's defaults are max_iters 2000, confidence 0.995.
+ * SIFT_ERR_INVALID unless 0 < confidence < 1, threshold > 0, n >= 0. */
+int sift_find_homography(sift_ctx *ctx, const float *src_xy, const float *dst_xy, int n, double reproj_threshold,
+                         int max_iters, double confidence, double H[9], uint8_t *mask, sift_homography_info *info);
+
 /* ---- synthetic inputs (host) ---------------------------------------------- */
 /* Dead-leaves frame generator: splitmix64 seeded with
  * seed*0x9E3779B97F4A7C15 + frame_index; w*h/128 discs painted over a 128-gray

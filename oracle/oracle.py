@@ -25,8 +25,8 @@ STATS_DTYPE = np.dtype([(f, "<i8") for f in STATS_FIELDS])
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    src = os.path.join(_HERE, "sift_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("sift_oracle.c", "homography_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libsift_oracle.so"])
     return _LIB_PATH
 
@@ -220,3 +220,57 @@ def min_dist_filter(dist):
     good = np.empty(len(dist), np.int32)
     n = lib().orc_min_dist_filter(dist.ctypes.data, len(dist), good.ctypes.data)
     return good[:n].copy()
+
+
+# ---- findHomography(RANSAC) restatement (homography_oracle.c; parity unpinned) ----
+
+class HomographyInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("found", "iterations", "best_iteration", "inliers", "lm_iterations")]
+
+
+def _pts(a):
+    return np.ascontiguousarray(a, np.float32).reshape(-1, 2)
+
+
+def find_homography(src, dst, thresh=3.0, max_iters=2000, confidence=0.995):
+    """Returns (H 3x3 or None, mask uint8[N], info dict)."""
+    src, dst = _pts(src), _pts(dst)
+    n = src.shape[0]
+    H = np.zeros(9)
+    mask = np.zeros(max(n, 1), np.uint8)
+    info = HomographyInfo()
+    L = lib()
+    L.orc_find_homography(C.c_void_p(src.ctypes.data), C.c_void_p(dst.ctypes.data), n, C.c_double(thresh), max_iters,
+                          C.c_double(confidence), C.c_void_p(H.ctypes.data), C.c_void_p(mask.ctypes.data), C.byref(info))
+    d = {k: getattr(info, k) for k, _ in HomographyInfo._fields_}
+    return (H.reshape(3, 3) if info.found else None), mask[:n], d
+
+
+def homography_rng_sequence(state, n):
+    out = np.zeros(n, np.uint32)
+    lib().orc_h_rng_sequence(C.c_uint64(state), n, C.c_void_p(out.ctypes.data))
+    return out
+
+
+def homography_subsets(src, dst, n_iters):
+    src, dst = _pts(src), _pts(dst)
+    out = np.zeros((n_iters, 4), np.int32)
+    k = lib().orc_h_subsets(C.c_void_p(src.ctypes.data), C.c_void_p(dst.ctypes.data), src.shape[0], n_iters,
+                            C.c_void_p(out.ctypes.data))
+    return out[:k]
+
+
+def homography_kernel(src, dst):
+    src, dst = _pts(src), _pts(dst)
+    H = np.zeros(9)
+    ok = lib().orc_h_kernel(C.c_void_p(src.ctypes.data), C.c_void_p(dst.ctypes.data), src.shape[0], C.c_void_p(H.ctypes.data))
+    return H.reshape(3, 3) if ok else None
+
+
+def homography_inliers(src, dst, H, thresh=3.0):
+    src, dst = _pts(src), _pts(dst)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    mask = np.zeros(max(src.shape[0], 1), np.uint8)
+    n = lib().orc_h_inliers(C.c_void_p(src.ctypes.data), C.c_void_p(dst.ctypes.data), src.shape[0], C.c_void_p(H.ctypes.data),
+                            C.c_double(thresh), C.c_void_p(mask.ctypes.data))
+    return n, mask[:src.shape[0]]

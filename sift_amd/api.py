@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "sift_batch_counts", "sift_batch_download", "sift_batch_result_device_ptrs", "sift_batch_get_level",
     "sift_batch_get_candidates", "sift_batch_get_oriented", "sift_batch_run_profiled", "sift_knn2_u8",
     "sift_knn2_f32", "sift_knn2_device", "sift_knn2_merge_device", "sift_match_min_dist_filter",
+    "sift_find_homography",
     "sift_synth_dead_leaves", "sift_synth_descriptors", "sift_synth_queries",
 )
 
@@ -58,6 +59,11 @@ class _FrameCounts(C.Structure):
 class _Result(C.Structure):
     _fields_ = [("n", C.c_int32), ("octaves", C.c_int32), ("keypoints", C.c_void_p),
                 ("descriptors", C.c_void_p), ("counts", _FrameCounts)]
+
+
+class _HomographyInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("found", "iterations", "best_iteration", "inliers", "lm_iterations", "hypotheses_scored")]
 
 
 class _StageTimes(C.Structure):
@@ -129,6 +135,7 @@ def lib():
     L.sift_knn2_device.argtypes = [vp, vp, ci, vp, ci, ci, vp]
     L.sift_knn2_merge_device.argtypes = [vp, vp, ci, ci, vp, vp]
     L.sift_match_min_dist_filter.argtypes = [vp, ci, vp, C.POINTER(C.c_int32)]
+    L.sift_find_homography.argtypes = [vp, vp, vp, ci, C.c_double, ci, C.c_double, vp, vp, C.POINTER(_HomographyInfo)]
     L.sift_synth_dead_leaves.argtypes = [u64, u64, ci, ci, vp]
     L.sift_synth_descriptors.argtypes = [u64, i64, vp]
     L.sift_synth_queries.argtypes = [u64, vp, i64, i64, vp]
@@ -254,6 +261,22 @@ class Context:
             t = np.ascontiguousarray(t, np.float32)
             _check(lib().sift_knn2_f32(self._h, q.ctypes.data, nq, t.ctypes.data, nt, out.ctypes.data, acc.ctypes.data))
         return out, acc
+
+    def find_homography(self, src, dst, reproj_threshold=3.0, max_iters=2000, confidence=0.995):
+        """findHomography(src, dst, RANSAC, reproj_threshold, mask) (main.cpp:105).  src, dst: Nx2 float32.
+        Returns (H or None, mask uint8[N], info dict)."""
+        src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+        dst = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+        if src.shape != dst.shape:
+            raise ValueError("src and dst must hold the same number of points")
+        n = src.shape[0]
+        H = np.zeros(9, np.float64)
+        mask = np.zeros(max(n, 1), np.uint8)
+        info = _HomographyInfo()
+        _check(lib().sift_find_homography(self._h, src.ctypes.data, dst.ctypes.data, n, reproj_threshold, max_iters,
+                                          confidence, H.ctypes.data, mask.ctypes.data, C.byref(info)))
+        d = {k: getattr(info, k) for k, _ in _HomographyInfo._fields_}
+        return (H.reshape(3, 3) if info.found else None), mask[:n], d
 
     def knn2_device(self, d_q, nq, d_t, nt, train_base, d_out):
         _check(lib().sift_knn2_device(self._h, d_q, nq, d_t, nt, train_base, d_out))

@@ -73,6 +73,8 @@ struct sift_ctx {
     size_t knn_scratch_bytes = 0;
     void *knn_io = nullptr;  // device staging of the host-buffer matcher calls
     size_t knn_io_bytes = 0;
+    void *h_work = nullptr;  // device workspace of sift_find_homography
+    size_t h_work_bytes = 0;
     sift_batch *cached = nullptr;  // workspace of the single-image calls
 };
 
@@ -122,7 +124,7 @@ int sift_ctx_create(int device, sift_ctx **out) {
         delete c;
         return fail(SIFT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    if (pyramid_init_attributes() != 0) {
+    if (pyramid_init_attributes() != 0 || homography_init_attributes() != 0) {
         hipStreamDestroy(c->stream);
         delete c;
         return fail(SIFT_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -138,6 +140,7 @@ int sift_ctx_destroy(sift_ctx *ctx) {
     if (ctx->cached) sift_batch_destroy(ctx->cached);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
     if (ctx->knn_io) hipFree(ctx->knn_io);
+    if (ctx->h_work) hipFree(ctx->h_work);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SIFT_OK;
@@ -685,6 +688,27 @@ int sift_match_min_dist_filter(const sift_knn2 *knn, int nq, int32_t *good_idx, 
         if (dist < 3 * min_dist) good_idx[g++] = i;  // main.cpp:88
     }
     *n_good = g;
+    return SIFT_OK;
+}
+
+// ---- homography -----------------------------------------------------------------
+
+int sift_find_homography(sift_ctx *ctx, const float *src_xy, const float *dst_xy, int n, double reproj_threshold,
+                         int max_iters, double confidence, double H[9], uint8_t *mask, sift_homography_info *info) {
+    if (!ctx || !H || (n > 0 && (!src_xy || !dst_xy))) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (n < 0) return fail(SIFT_ERR_INVALID, "negative count");
+    if (!(confidence > 0 && confidence < 1)) return fail(SIFT_ERR_INVALID, "confidence must lie in (0, 1)");
+    if (!(reproj_threshold > 0)) return fail(SIFT_ERR_INVALID, "reprojection threshold must be positive");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t need = homography_workspace_bytes(n, HOMOGRAPHY_CHUNK);
+    if (need > ctx->h_work_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc = ensure_bytes(&ctx->h_work, &ctx->h_work_bytes, need);
+        if (rc) return rc;
+    }
+    sift_homography_info local;
+    HIP_TRY(find_homography_ransac(ctx->stream, ctx->h_work, src_xy, dst_xy, n, reproj_threshold, max_iters, confidence, H,
+                                   mask, info ? info : &local));
     return SIFT_OK;
 }
 

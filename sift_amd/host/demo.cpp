@@ -1,6 +1,7 @@
-// Counterpart of the reference's src/main.cpp up to the match list
-// (main.cpp:22-93): extract features of every image, then match the last image
-// (the reference) against each of the others and report the good matches.
+// Counterpart of the reference's src/main.cpp up to the homography
+// (main.cpp:22-105): extract features of every image, then match the last image
+// (the reference) against each of the others, report the good matches and
+// estimate the homography that maps the reference onto the image.
 // Images are PNG or binary PGM/PPM files, read by sift_io::imread with the
 // conventions of cv::imread (BGR, 8-bit, 3 channels).
 //
@@ -9,6 +10,7 @@
 #include <cstdio>
 #include <iostream>
 #include <sstream>
+#include <vector>
 
 #include "image_io.hpp"
 #include "sift.hpp"
@@ -59,6 +61,18 @@ int main(int argc, char **argv) {
         for (const auto &m : matches) ratio += m.ratio_ok;
         std::cerr << "Good Matches found:" << good.size() << std::endl;  // main.cpp:93
         std::cout << "matches " << matches.size() << " good " << good.size() << " ratio_test " << ratio << std::endl;
+        std::vector<cv::Point2f> obj, scene;  // main.cpp:92-101
+        for (const auto &gm : good) {
+            obj.push_back(s_ref.keypoints[gm.queryIdx].pt);
+            scene.push_back(s.keypoints[gm.trainIdx].pt);
+        }
+        const auto hr = sift::find_homography(obj, scene, 3);  // main.cpp:105
+        std::cout << "homography found " << hr.found << " inliers " << hr.inliers << " iterations " << hr.iterations << std::endl;
+        if (hr.found) {
+            std::cout.precision(17);
+            for (int r = 0; r < 3; r++) std::cout << "H " << hr.H[3 * r] << " " << hr.H[3 * r + 1] << " " << hr.H[3 * r + 2] << std::endl;
+            std::cout.precision(6);
+        }
     }
     return 0;
 }

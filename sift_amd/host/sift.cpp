@@ -166,4 +166,21 @@ std::vector<match_result> good_matches(const std::vector<match_result> &matches)
     return good;
 }
 
+homography_result find_homography(const std::vector<cv::Point2f> &obj, const std::vector<cv::Point2f> &scene,
+                                  double ransacReprojThreshold, int maxIters, double confidence) {
+    if (obj.size() != scene.size()) throw std::runtime_error("find_homography: obj and scene differ in length");
+    static_assert(sizeof(cv::Point2f) == 2 * sizeof(float), "Point2f is an (x, y) float pair");
+    const int n = (int)obj.size();
+    homography_result r;
+    r.mask.assign((size_t)n, 0);
+    sift_homography_info info{};
+    check(sift_find_homography(context(), n ? &obj[0].x : nullptr, n ? &scene[0].x : nullptr, n, ransacReprojThreshold, maxIters,
+                               confidence, r.H, r.mask.data(), &info),
+          "sift_find_homography");
+    r.found = info.found != 0;
+    r.iterations = info.iterations;
+    r.inliers = info.inliers;
+    return r;
+}
+
 }  // namespace sift

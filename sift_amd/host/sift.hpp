@@ -75,6 +75,20 @@ std::vector<match_result> knn_match(const cv::Mat &query, const cv::Mat &train);
 // main.cpp:77-91: min_dist starts at 100; good <=> distance < 3 * min_dist.
 std::vector<match_result> good_matches(const std::vector<match_result> &matches);
 
+// cv::findHomography(obj, scene, RANSAC, ransacReprojThreshold, mask) as main.cpp:105
+// calls it: the 3x3 matrix (row-major) that maps obj to scene and the inlier mask.
+// `found` is false where OpenCV returns an empty matrix (fewer than 4 points, or
+// no usable model); H is then all zeros.
+struct homography_result {
+    bool found = false;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<unsigned char> mask;  // one byte per correspondence, 1 = inlier
+    int iterations = 0;               // RANSAC iterations
+    int inliers = 0;
+};
+homography_result find_homography(const std::vector<cv::Point2f> &obj, const std::vector<cv::Point2f> &scene,
+                                  double ransacReprojThreshold = 3, int maxIters = 2000, double confidence = 0.995);
+
 }  // namespace sift
 
 #endif
