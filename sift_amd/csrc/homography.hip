@@ -33,21 +33,13 @@ namespace {
 
 #define SA_HOSTDEV __host__ __device__ __forceinline__
 
-// ---- element access: contiguous on the host, lane-interleaved in LDS ------------
+// ---- element access ------------------------------------------------------------
 template <class T>
 struct Plain {
     T *p;
     SA_HOSTDEV T &operator[](int i) const { return p[i]; }
     SA_HOSTDEV Plain offset(int i) const { return Plain{p + i}; }
 };
-constexpr int HT = 64;  // 4-point models per workgroup (one per lane)
-template <class T>
-struct Interleaved {
-    T *p;  // element i of this lane lives at p[i * HT]
-    SA_HOSTDEV T &operator[](int i) const { return p[i * HT]; }
-    SA_HOSTDEV Interleaved offset(int i) const { return Interleaved{p + i * HT}; }
-};
-
 // hypot as cv::hypot computes it (core/base.hpp)
 SA_HOSTDEV double scaled_hypot(double a, double b) {
     a = fabs(a);
@@ -243,26 +235,216 @@ SA_HOSTDEV float reprojection_error(const ModelF &f, float2 M, float2 m) {
 
 // ---- device side ---------------------------------------------------------------
 
-constexpr int LDS_DOUBLES_PER_MODEL = 81 + 81 + 9;  // normal matrix, eigenvectors, eigenvalues
-constexpr size_t MODELS_LDS_BYTES = (size_t)HT * (LDS_DOUBLES_PER_MODEL * sizeof(double) + 18 * sizeof(int));
+// A 4-point model per team of 16 lanes, four teams per wave.  The 9x9 eigenproblem is
+// the long pole (a hundred-odd dependent Jacobi rotations), so a team splits each rotation:
+// lane i rotates the pair of matrix entries and the pair of eigenvector entries of index i,
+// the pivot caches (one per lane: the row maxima in lanes 0..7, the column maxima in lanes
+// 8..15) are searched and refreshed with 16-lane arg-max reductions that prefer the lowest
+// position among equals, which is what the sequential scans with their strict comparisons
+// pick.  Every entry is computed from the same operands by the same operations as in
+// jacobi_symmetric, so the result has the same bits.
+constexpr int TEAM = 16, TEAMS = 4;
 
-// One thread per 4-point subset: models[9*h..] and valid[h].
-__global__ __launch_bounds__(HT) void k_h_models(const float2 *__restrict__ src, const float2 *__restrict__ dst,
-                                                 const int *__restrict__ subsets, int nh, double *__restrict__ models,
-                                                 uint8_t *__restrict__ valid) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int t = threadIdx.x, h = blockIdx.x * HT + t;
-    if (h >= nh) return;  // no barrier below
-    const Interleaved<double> A{lds + t}, V{lds + 81 * HT + t}, W{lds + 162 * HT + t};
-    int *ints = reinterpret_cast<int *>(lds + LDS_DOUBLES_PER_MODEL * HT);
-    const Interleaved<int> indR{ints + t}, indC{ints + 9 * HT + t};
-    const int *sub = subsets + 4 * (size_t)h;
-    double H[9];
-    const int ok = fit_dlt([&](int i) { return src[sub[i]]; }, [&](int i) { return dst[sub[i]]; }, 4, A, W, V, indR, indC, H);
-    valid[h] = (uint8_t)ok;
-    if (ok) {
+// Lane exchange inside a row of 16 lanes with DPP moves (no LDS round trip): the two quad
+// permutations make every lane hold its quad's result, the rotations by 4 and 8 lanes then
+// combine the four quads.
+template <int CTRL>
+__device__ __forceinline__ int dpp_int(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(double &v, int &key) {
+    const double ov = __hiloint2double(dpp_int<CTRL>(__double2hiint(v)), dpp_int<CTRL>(__double2loint(v)));
+    const int okey = dpp_int<CTRL>(key);
+    const bool take = ov > v || (ov == v && okey < key);
+    v = take ? ov : v;
+    key = take ? okey : key;
+}
+// All 16 lanes of a team end with the largest v and the key that came with it; among equal
+// values the smallest key wins.
+__device__ __forceinline__ void team_argmax(double &v, int &key) {
+    argmax_step<0xB1>(v, key);   // quad_perm [1,0,3,2]
+    argmax_step<0x4E>(v, key);   // quad_perm [2,3,0,1]
+    argmax_step<0x124>(v, key);  // row_ror:4
+    argmax_step<0x128>(v, key);  // row_ror:8
+}
+
+__global__ __launch_bounds__(TEAM *TEAMS) void k_h_models(const float2 *__restrict__ src, const float2 *__restrict__ dst,
+                                                          const int *__restrict__ subsets, int nh,
+                                                          double *__restrict__ models, uint8_t *__restrict__ valid) {
+    __shared__ double sA[TEAMS][81], sV[TEAMS][81], sW[TEAMS][9], sL[TEAMS][4][18];
+    __shared__ int sPerm[TEAMS][9];
+    const int team = threadIdx.x / TEAM, j = threadIdx.x % TEAM;
+    const int h = blockIdx.x * TEAMS + team;
+    const bool live = h < nh;
+    const int *sub = subsets + 4 * (size_t)(live ? h : nh - 1);  // idle teams shadow the last model and write nothing
+    double *A = sA[team], *V = sV[team], *W = sW[team];
+
+    // normalisation, by every lane (same values): fit_dlt with count = 4
+    float2 M[4], m[4];
 #pragma unroll
-        for (int i = 0; i < 9; i++) models[9 * (size_t)h + i] = H[i];
+    for (int p = 0; p < 4; p++) {
+        M[p] = src[sub[p]];
+        m[p] = dst[sub[p]];
+    }
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        cmx += m[p].x;
+        cmy += m[p].y;
+        cMx += M[p].x;
+        cMy += M[p].y;
+    }
+    cmx /= 4;
+    cmy /= 4;
+    cMx /= 4;
+    cMy /= 4;
+    double sMx = 0, sMy = 0, smx = 0, smy = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        smx += fabs(m[p].x - cmx);
+        smy += fabs(m[p].y - cmy);
+        sMx += fabs(M[p].x - cMx);
+        sMy += fabs(M[p].y - cMy);
+    }
+    const bool ok = !(fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON);
+    smx = ok ? 4 / smx : 1.0;  // a degenerate subset goes through the motions on finite numbers and is flagged invalid
+    smy = ok ? 4 / smy : 1.0;
+    sMx = ok ? 4 / sMx : 1.0;
+    sMy = ok ? 4 / sMy : 1.0;
+
+    // the two constraint rows of point j (lanes 0..3)
+    if (j < 4) {
+        const float2 Mj = j == 0 ? M[0] : j == 1 ? M[1] : j == 2 ? M[2] : M[3];
+        const float2 mj = j == 0 ? m[0] : j == 1 ? m[1] : j == 2 ? m[2] : m[3];
+        const double x = (mj.x - cmx) * smx, y = (mj.y - cmy) * smy;
+        const double X = (Mj.x - cMx) * sMx, Y = (Mj.y - cMy) * sMy;
+        double *L = sL[team][j];
+        L[0] = X, L[1] = Y, L[2] = 1, L[3] = 0, L[4] = 0, L[5] = 0, L[6] = -x * X, L[7] = -x * Y, L[8] = -x;
+        L[9] = 0, L[10] = 0, L[11] = 0, L[12] = X, L[13] = Y, L[14] = 1, L[15] = -y * X, L[16] = -y * Y, L[17] = -y;
+    }
+    __syncthreads();
+    // row j of the normal matrix (upper part, mirrored), identity eigenvectors, diagonal
+    if (j < 9) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            if (k >= j) {
+                double acc = 0;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const double *L = sL[team][p];
+                    acc = acc + (L[j] * L[k] + L[9 + j] * L[9 + k]);
+                }
+                A[9 * j + k] = acc;
+                A[9 * k + j] = acc;
+                if (k == j) W[j] = acc;
+            }
+            V[9 * j + k] = k == j ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+
+    const Plain<double> Am{A};
+    int my_ind = j < 8 ? row_pivot(Am, 9, j) : col_pivot(Am, 9, j - 7);  // indR[j] | indC[j-7]
+    bool active = true;
+    for (int it = 0; it < 9 * 9 * 30; it++) {
+        // pivot: first maximum over the row caches 0..7, then the column caches 1..8
+        const int ck = j < 8 ? j : my_ind, cl = j < 8 ? my_ind : j - 7;
+        double best = fabs(A[9 * ck + cl]);
+        int key = j * 256 + ck * 16 + cl;  // position first: the earliest of equal maxima wins
+        team_argmax(best, key);
+        const int k = (key >> 4) & 15, l = key & 15;
+        const double p = A[9 * k + l];
+        if (fabs(p) <= DBL_EPSILON) active = false;
+        if (!__any(active)) break;
+        const double wk = W[k], wl = W[l];
+        const double y = (wl - wk) * 0.5;
+        double t = fabs(y) + scaled_hypot(p, y);
+        double s = scaled_hypot(p, t);
+        const double c = t / s;
+        s = p / s;
+        t = (p / t) * p;
+        if (y < 0) s = -s, t = -t;
+        // lane i < 9 owns the entry pair of index i (none for i = k, l) and the eigenvector pair of column i
+        const bool has_v = j < 9, has_a = has_v && j != k && j != l;
+        const int jj = has_v ? j : 0;
+        const int a0i = jj < k ? 9 * jj + k : 9 * k + jj, a1i = jj < l ? 9 * jj + l : 9 * l + jj;
+        const double a0 = A[a0i], a1 = A[a1i], v0 = V[9 * k + jj], v1 = V[9 * l + jj];
+        __syncthreads();  // every lane has read what it rotates (and p) before anything is overwritten
+        if (active) {
+            if (has_a) {
+                A[a0i] = a0 * c - a1 * s;
+                A[a1i] = a0 * s + a1 * c;
+            }
+            if (has_v) {
+                V[9 * k + jj] = v0 * c - v1 * s;
+                V[9 * l + jj] = v0 * s + v1 * c;
+            }
+            if (j == 0) {
+                A[9 * k + l] = 0;
+                W[k] = wk - t;
+                W[l] = wl + t;
+            }
+        }
+        __syncthreads();
+        // refresh the caches of rows and columns k and l
+        double rk = j > k && j < 9 ? fabs(A[9 * k + j]) : -1.0, ck2 = j < k ? fabs(A[9 * j + k]) : -1.0;
+        double rl = j > l && j < 9 ? fabs(A[9 * l + j]) : -1.0, cl2 = j < l ? fabs(A[9 * j + l]) : -1.0;
+        int prk = j, pck = j, prl = j, pcl = j;
+        team_argmax(rk, prk);
+        team_argmax(ck2, pck);
+        team_argmax(rl, prl);
+        team_argmax(cl2, pcl);
+        if (active) {
+            if (j < 8) {
+                if (j == k) my_ind = prk;  // k < l <= 8
+                if (j == l) my_ind = prl;
+            } else {
+                const int i = j - 7;
+                if (i == k) my_ind = pck;  // k >= 1 here
+                if (i == l) my_ind = pcl;
+            }
+        }
+    }
+    __syncthreads();
+    // which eigenvector does the descending selection sort leave in the last row?
+    if (j == 0) {
+        int *perm = sPerm[team];
+        for (int i = 0; i < 9; i++) perm[i] = i;
+        for (int k = 0; k < 8; k++) {
+            int mi = k;
+            for (int i = k + 1; i < 9; i++)
+                if (W[mi] < W[i]) mi = i;
+            if (k != mi) {
+                const double w = W[mi];
+                W[mi] = W[k];
+                W[k] = w;
+                const int q = perm[mi];
+                perm[mi] = perm[k];
+                perm[k] = q;
+            }
+        }
+    }
+    __syncthreads();
+    if (j == 0 && live) {
+        const double *h0 = V + 9 * sPerm[team][8];
+        const double inv_to[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+        const double t_from[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+        double tmp[9], out[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) tmp[3 * r + q] = inv_to[3 * r] * h0[q] + inv_to[3 * r + 1] * h0[3 + q] + inv_to[3 * r + 2] * h0[6 + q];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) out[3 * r + q] = tmp[3 * r] * t_from[q] + tmp[3 * r + 1] * t_from[3 + q] + tmp[3 * r + 2] * t_from[6 + q];
+        const double scale = 1. / out[8];
+        valid[h] = (uint8_t)ok;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) models[9 * (size_t)h + i] = out[i] * scale;
+        }
     }
 }
 
@@ -515,13 +697,6 @@ class Refiner {
 
 }  // namespace
 
-int homography_init_attributes() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_models), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)MODELS_LDS_BYTES) == hipSuccess
-               ? 0
-               : -1;
-}
-
 size_t homography_workspace_bytes(int n, int chunk) {
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return 2 * up((size_t)n * sizeof(float2)) + up((size_t)chunk * 4 * sizeof(int)) + up((size_t)chunk * 9 * sizeof(double)) +
@@ -592,7 +767,7 @@ hipError_t find_homography_ransac(hipStream_t st, void *workspace, const float *
             }
             if (have == 0) break;
             H_TRY(hipMemcpyAsync(d_subsets, subsets.data(), (size_t)have * 4 * sizeof(int), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_h_models, dim3((have + HT - 1) / HT), dim3(HT), MODELS_LDS_BYTES, st, d_src, d_dst, d_subsets, have,
+            hipLaunchKernelGGL(k_h_models, dim3((have + TEAMS - 1) / TEAMS), dim3(TEAM * TEAMS), 0, st, d_src, d_dst, d_subsets, have,
                                d_models, d_valid);
             hipLaunchKernelGGL(k_h_score, dim3((have + SCORE_WAVES - 1) / SCORE_WAVES), dim3(64 * SCORE_WAVES), 0, st, d_src, d_dst,
                                n, d_models, d_valid, have, thresh2, d_counts);

@@ -40,7 +40,6 @@ void launch_knn2_merge(hipStream_t st, const sift_knn2 *parts, int nparts, int n
 // homography.hip
 constexpr int HOMOGRAPHY_CHUNK = 1024;       // RANSAC iterations evaluated per launch
 constexpr int HOMOGRAPHY_FIRST_CHUNK = 256;  // ... in the first launch (the budget usually collapses within it)
-int homography_init_attributes();
 size_t homography_workspace_bytes(int n, int chunk);
 hipError_t find_homography_ransac(hipStream_t st, void *workspace, const float *src_xy, const float *dst_xy, int n,
                                   double threshold, int max_iters, double confidence, double H[9], uint8_t *mask,
