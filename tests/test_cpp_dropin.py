@@ -93,3 +93,13 @@ def test_demo_matches_oracle(sift_lib, oracle, lenna_bgr, lenna_rotated_bgr, gol
     line = [l for l in out.stdout.splitlines() if l.startswith("matches")][0].split()
     assert int(line[1]) == 1112 and int(line[3]) == len(good) and int(line[5]) == int(acc.sum())
     assert "Good Matches found:%d" % len(good) in out.stderr
+    # homography over the good matches (main.cpp:92-105) equals the CPU restatement's, printed with 17 digits
+    kq, kt = golden("lenna")["keypoints"], golden("lennarotated")["keypoints"]
+    obj = np.c_[kq["x"][good], kq["y"][good]].astype(np.float32)
+    scene = np.c_[kt["x"][i1[good]], kt["y"][i1[good]]].astype(np.float32)
+    H, mask, info = oracle.find_homography(obj, scene)
+    hline = [l for l in out.stdout.splitlines() if l.startswith("homography")][0].split()
+    assert int(hline[2]) == info["found"] and int(hline[4]) == info["inliers"] and int(hline[6]) == info["iterations"]
+    if info["found"]:
+        got = np.array([[float(v) for v in l.split()[1:]] for l in out.stdout.splitlines() if l.startswith("H ")])
+        assert np.array_equal(got, H)
