@@ -176,6 +176,7 @@ cv::Mat imread(const std::string &path) {
     if (!f) return cv::Mat();
     std::vector<unsigned char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     if (buf.size() >= 8 && buf[0] == 0x89 && buf[1] == 'P') return decode_png(buf.data(), buf.size());
+    if (buf.size() >= 4 && buf[0] == 0xFF && buf[1] == 0xD8) return decode_jpeg(buf.data(), buf.size());
     if (buf.size() >= 7 && buf[0] == 'P' && (buf[1] == '5' || buf[1] == '6')) return read_pnm(buf);
     return cv::Mat();
 }

@@ -1,6 +1,10 @@
-"""sift_amd/host/image_io: PNG / PNM files -> 8-bit BGR, the way cv::imread hands images to the
-reference's main.cpp:30.  Checked against PIL on the reference's own pictures and against
-hand-built PNGs of every colour type, bit depth and scanline filter."""
+"""sift_amd/host/image_io: PNG / JPEG / PNM files -> 8-bit BGR, the way cv::imread hands images to the
+reference's main.cpp:30.  PNG: checked against PIL on the reference's own pictures and against
+hand-built PNGs of every colour type, bit depth and scanline filter.  JPEG: checked bit for bit
+against what libjpeg-turbo (through Pillow, scripts/make_jpeg_fixtures.py) decodes, on small files of
+every coding variant and, where /root/reference is present, on all of the reference's res/*.jpg."""
+import glob
+import json
 import os
 import struct
 import subprocess
@@ -19,7 +23,7 @@ def checker(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("imgio") / "image_io_check")
     subprocess.check_call(["g++", "-O2", "-std=c++20", "-I" + HOST, "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "image_io_check.cpp"), os.path.join(HOST, "image_io.cpp"),
-                           "-lz", "-o", exe])
+                           os.path.join(HOST, "jpeg_decode.cpp"), "-lz", "-o", exe])
 
     def run(*paths):
         out = subprocess.run([exe, *map(str, paths)], check=True, capture_output=True, text=True).stdout
@@ -129,3 +133,69 @@ def test_pnm_and_unreadable_files(checker, tmp_path):
     assert got[0] == expect(np.ascontiguousarray(rgb[:, :, ::-1]))
     assert got[1] == expect(np.stack([gray] * 3, axis=2))
     assert got[2] == ["EMPTY"] and got[3] == ["EMPTY"] and got[4] == ["EMPTY"]
+
+
+# ---- JPEG -------------------------------------------------------------------------------------
+
+JPEG_DIR = os.path.join(GOLDEN, "jpeg")
+JPEG_EXPECTED = json.load(open(os.path.join(JPEG_DIR, "expected.json")))
+
+
+def as_list(e):
+    return [str(e["w"]), str(e["h"]), str(e["sum"]), str(e["hash"])]
+
+
+def test_jpeg_variants_decode_like_libjpeg_turbo(checker):
+    """Baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0, odd and tiny sizes (narrow components take the
+    non-interpolating upsampler), optimised Huffman tables, 16-bit-range coefficients (quality 100) and
+    coarse ones (quality 10), restart intervals, grey, and the eight EXIF orientations."""
+    names = sorted(JPEG_EXPECTED["generated"])
+    assert len(names) >= 32
+    got = checker(*[os.path.join(JPEG_DIR, n) for n in names])
+    for n, g in zip(names, got):
+        assert g == as_list(JPEG_EXPECTED["generated"][n]), n
+
+
+def test_jpeg_fixture_expectations_still_match_pillow():
+    """The expectations are what Pillow's libjpeg-turbo decodes today, with cv::imread's EXIF handling."""
+    from PIL import Image
+    for n in ("base_420_odd.jpg", "prog_422_odd.jpg", "exif_6.jpg", "grey_prog.jpg"):
+        im = Image.open(os.path.join(JPEG_DIR, n))
+        o = im.getexif().get(0x0112) or 1
+        bgr = np.array(im.convert("RGB"))[:, :, ::-1]
+        if o == 6:  # transpose, then flip horizontally: a quarter turn clockwise
+            bgr = bgr.transpose(1, 0, 2)[:, ::-1]
+        assert expect(np.ascontiguousarray(bgr)) == as_list(JPEG_EXPECTED["generated"][n]), n
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/res"), reason="the reference checkout is not on this machine")
+def test_reference_jpegs_decode_like_libjpeg_turbo(checker):
+    """All twenty res/*.jpg|jpeg of the reference (baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0, a restart
+    interval, an Adobe marker, up to 2000 x 3008), against hashes of Pillow's decode recorded by
+    scripts/make_jpeg_fixtures.py."""
+    names = sorted(JPEG_EXPECTED["reference_res"])
+    assert len(names) == 20
+    got = checker(*[os.path.join("/root/reference/res", n) for n in names])
+    for n, g in zip(names, got):
+        assert g == as_list(JPEG_EXPECTED["reference_res"][n]), n
+
+
+def test_broken_and_unsupported_jpegs_yield_empty(checker, tmp_path):
+    good = open(os.path.join(JPEG_DIR, "base_420.jpg"), "rb").read()
+    sof = good.index(b"\xff\xc0")
+    cases = {
+        "not.jpg": b"\xff\xd8" + b"\x00" * 40,                      # SOI, then nothing usable
+        "noscan.jpg": good[:sof] + b"\xff\xd9",                     # tables only
+        "arith.jpg": good[:sof + 1] + b"\xc9" + good[sof + 2:],      # SOF9: arithmetic coding
+        "p12.jpg": good[:sof + 4] + b"\x0c" + good[sof + 5:],        # 12-bit samples
+        "cmyk.jpg": good[:sof + 9] + b"\x04" + good[sof + 10:],      # four components
+        "cutseg.jpg": good[:sof + 6],                                # frame header cut short
+    }
+    for n, b in cases.items():
+        (tmp_path / n).write_bytes(b)
+    got = checker(*[tmp_path / n for n in cases])
+    assert all(g == ["EMPTY"] for g in got), got
+    # a file cut in the middle of its entropy-coded data still yields a full-sized picture (zeros are fed), as libjpeg does
+    (tmp_path / "cut.jpg").write_bytes(good[:len(good) * 2 // 3])
+    g = checker(tmp_path / "cut.jpg")[0]
+    assert g[:2] == as_list(JPEG_EXPECTED["generated"]["base_420.jpg"])[:2]
