@@ -69,6 +69,10 @@ int sift_ctx_destroy(sift_ctx *ctx);
 /* The HIP stream (hipStream_t) every call of this context enqueues on. */
 int sift_ctx_stream(sift_ctx *ctx, void **stream);
 int sift_ctx_synchronize(sift_ctx *ctx);
+/* Initial capacity (candidates and keypoints per frame) of the workspace behind sift_extract_*; 0 restores
+ * the default, max(8192, pixels/16).  The reference's vectors (sift.hpp:93-94) grow without bound: when a frame
+ * exceeds the capacity, sift_extract_* runs it again in a larger workspace, so this is a memory knob only. */
+int sift_ctx_set_single_image_capacity(sift_ctx *ctx, int max_keypoints);
 
 /* ---- geometry helpers (host only) ---------------------------------------- */
 /* octaves = round(log2(min(w,h))) on the input size (sift.cpp:36). */

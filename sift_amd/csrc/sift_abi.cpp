@@ -76,6 +76,7 @@ struct sift_ctx {
     void *h_work = nullptr;  // device workspace of sift_find_homography
     size_t h_work_bytes = 0;
     sift_batch *cached = nullptr;  // workspace of the single-image calls
+    int single_cap = 0;            // its initial per-frame list capacity (0: the batch default)
 };
 
 struct sift_batch {
@@ -143,6 +144,18 @@ int sift_ctx_destroy(sift_ctx *ctx) {
     if (ctx->h_work) hipFree(ctx->h_work);
     hipStreamDestroy(ctx->stream);
     delete ctx;
+    return SIFT_OK;
+}
+
+int sift_ctx_set_single_image_capacity(sift_ctx *ctx, int max_keypoints) {
+    if (!ctx || max_keypoints < 0) return fail(SIFT_ERR_INVALID, "bad argument");
+    ctx->single_cap = max_keypoints;
+    if (ctx->cached) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        sift_batch_destroy(ctx->cached);
+        ctx->cached = nullptr;
+    }
     return SIFT_OK;
 }
 
@@ -522,19 +535,33 @@ int sift_batch_get_oriented(sift_batch *b, int frame, int capacity, sift_keypoin
 static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, bool bgr, sift_result *out) {
     if (!ctx || !img || !out) return fail(SIFT_ERR_INVALID, "NULL argument");
     std::memset(out, 0, sizeof(*out));
-    sift_batch *b = ctx->cached;
-    if (!b || b->w != w || b->h != h) {
-        if (b) sift_batch_destroy(b);
-        ctx->cached = nullptr;
-        int rc = sift_batch_create(ctx, w, h, 1, 0, &b);
-        if (rc) return rc;
-        ctx->cached = b;
-    }
-    int rc = bgr ? sift_batch_upload_bgr8(b, 0, img, stride) : sift_batch_upload_gray8(b, 0, img, stride);
-    if (rc) return rc;
-    if ((rc = sift_batch_run(b, 1))) return rc;
+    // The reference's lists grow without bound; here a frame whose candidates or keypoints exceed the
+    // workspace is run again in a larger one (the counters keep counting past the capacity).
+    sift_batch *b = nullptr;
     sift_frame_counts fc;
-    if ((rc = sift_batch_counts(b, 1, &fc))) return rc;
+    int want_cap = ctx->single_cap;
+    for (int attempt = 0;; attempt++) {
+        b = ctx->cached;
+        if (!b || b->w != w || b->h != h || (attempt > 0 && b->kp_cap < want_cap)) {
+            if (b) sift_batch_destroy(b);
+            ctx->cached = nullptr;
+            int rc = sift_batch_create(ctx, w, h, 1, want_cap, &b);
+            if (rc) return rc;
+            ctx->cached = b;
+        }
+        int rc = bgr ? sift_batch_upload_bgr8(b, 0, img, stride) : sift_batch_upload_gray8(b, 0, img, stride);
+        if (rc) return rc;
+        if ((rc = sift_batch_run(b, 1))) return rc;
+        rc = sift_batch_counts(b, 1, &fc);
+        if (rc == SIFT_ERR_OVERFLOW && attempt < 4) {
+            const int64_t seen = std::max<int64_t>(std::max(fc.candidates, fc.oriented), b->kp_cap);
+            if (seen > (int64_t)1 << 28) return rc;
+            want_cap = (int)(2 * seen);
+            continue;
+        }
+        if (rc) return rc;
+        break;
+    }
     out->counts = fc;
     out->octaves = b->pyr.octaves;
     out->n = fc.keypoints;
@@ -546,7 +573,7 @@ static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_
             return fail(SIFT_ERR_INVALID, "out of host memory");
         }
         int32_t n = 0;
-        rc = sift_batch_download(b, 0, fc.keypoints, out->keypoints, nullptr, out->descriptors, &n);
+        const int rc = sift_batch_download(b, 0, fc.keypoints, out->keypoints, nullptr, out->descriptors, &n);
         if (rc) {
             sift_result_free(out);
             return rc;

@@ -205,3 +205,20 @@ def test_4k_frame_runs_and_matches_oracle_counts(sift_lib, ctx, oracle):
     assert info["octaves"] == 11
     o = oracle.OracleSift(img).exec(threads=16, blur_threads=16)
     check_keypoints(kp, desc.astype(np.uint8), o.keypoints(), o.descriptors())
+
+
+@pytest.mark.gpu
+def test_single_image_call_grows_its_workspace(ctx, oracle, lenna_bgr):
+    """The reference's vectors grow without bound; the single-image call runs a frame that exceeds its
+    workspace again in a larger one.  Forced here by a tiny initial capacity."""
+    gray = oracle.bgr_to_gray(lenna_bgr)
+    o = oracle.OracleSift(gray).exec(threads=8, blur_threads=8)
+    try:
+        ctx.set_single_image_capacity(100)
+        kps, desc, info = ctx.extract(gray)
+        assert info["candidates"] == int(o.stats()["candidates"].sum()) > 100
+        check_keypoints(kps, desc, o.keypoints(), o.descriptors())
+        kps2, desc2, _ = ctx.extract(gray)  # the grown workspace is reused
+        assert np.array_equal(kps, kps2) and np.array_equal(desc, desc2)
+    finally:
+        ctx.set_single_image_capacity(0)
