@@ -51,6 +51,18 @@ def lenna_rotated_bgr():
 
 
 @pytest.fixture(scope="session")
+def school_pair(oracle):
+    """The reference's two-image panorama example (res/school_left.jpg, res/school_right.jpg) through the
+    CPU oracle: ((keypoints, descriptors) of left, of right).  Decoded with Pillow (libjpeg-turbo), gray by the
+    oracle's 15-bit formula."""
+    out = []
+    for n in ("school_left.jpg", "school_right.jpg"):
+        o = oracle.OracleSift(oracle.bgr_to_gray(_load_rgb(n)[:, :, ::-1].copy())).exec(threads=8, blur_threads=8)
+        out.append((o.keypoints(), o.descriptors()))
+    return out
+
+
+@pytest.fixture(scope="session")
 def known():
     import json
     return json.load(open(os.path.join(GOLDEN, "known_answers.json")))

@@ -103,3 +103,27 @@ def test_demo_matches_oracle(sift_lib, oracle, lenna_bgr, lenna_rotated_bgr, gol
     if info["found"]:
         got = np.array([[float(v) for v in l.split()[1:]] for l in out.stdout.splitlines() if l.startswith("H ")])
         assert np.array_equal(got, H)
+
+
+@pytest.mark.gpu
+def test_demo_on_the_school_panorama_pair(sift_lib, oracle, school_pair, tmp_path):
+    """The reference's two-image example, `smai res/school_left.jpg res/school_right.jpg`, through the C++
+    class: JPEG decoding (sift_io::imread), extraction, matching, the 3*min_dist filter and the homography.
+    168 good matches is the number README.md:306 publishes for it."""
+    build_host(sift_lib)
+    a, b = (os.path.join(ROOT, "tests", "golden", n) for n in ("school_left.jpg", "school_right.jpg"))
+    out = subprocess.run([os.path.join(HOST, "sift_demo"), a, b], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Size: [800 x 600]" in out.stderr
+    assert "Keypoints Calculated: 2686" in out.stderr and "Keypoints Calculated: 3472" in out.stderr
+    assert "Good Matches found:168" in out.stderr
+    (kl, dl), (kr, dr) = school_pair
+    i1, d1, *_ = oracle.knn2_u8(dr.astype(np.uint8), dl.astype(np.uint8), threads=8)
+    good = oracle.min_dist_filter(np.sqrt(d1.astype(np.float32)))
+    obj = np.c_[kr["x"][good], kr["y"][good]].astype(np.float32)
+    scene = np.c_[kl["x"][i1[good]], kl["y"][i1[good]]].astype(np.float32)
+    H, mask, info = oracle.find_homography(obj, scene)
+    hline = [l for l in out.stdout.splitlines() if l.startswith("homography")][0].split()
+    assert int(hline[2]) == 1 and int(hline[4]) == info["inliers"] and int(hline[6]) == info["iterations"]
+    got = np.array([[float(v) for v in l.split()[1:]] for l in out.stdout.splitlines() if l.startswith("H ")])
+    assert np.array_equal(got, H)

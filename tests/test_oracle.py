@@ -172,3 +172,22 @@ def test_min_dist_filter_oracle(oracle):
     dist = np.array([10.0, 31.0, 29.9, 500.0, 3.0, 8.9, 9.0], np.float32)
     assert oracle.min_dist_filter(dist).tolist() == [4, 5]       # min 3 -> good < 9
     assert oracle.min_dist_filter(np.array([400.0, 250.0], np.float32)).tolist() == [1]  # min_dist stays 100
+
+
+def test_school_pair_gives_the_published_168_good_matches(oracle, school_pair):
+    """README.md:306 (and docs/Final Report.md:306) caption the two-image panorama example with
+    "Feature matching (168 good matches)".  `smai school_left.jpg school_right.jpg` takes the last image as
+    the query (main.cpp:41, :75) and keeps matches with distance < 3 * min_dist (main.cpp:77-91): the oracle's
+    keypoints and descriptors, matched exactly, give the same 168 (the other argument order gives 167)."""
+    (kl, dl), (kr, dr) = school_pair
+    assert (len(kl), len(kr)) == (2686, 3472)
+    i1, d1, i2, d2, acc = oracle.knn2_u8(dr.astype(np.uint8), dl.astype(np.uint8), threads=8)
+    good = oracle.min_dist_filter(np.sqrt(d1.astype(np.float32)))
+    assert len(good) == 168
+    i1r, d1r, *_ = oracle.knn2_u8(dl.astype(np.uint8), dr.astype(np.uint8), threads=8)
+    assert len(oracle.min_dist_filter(np.sqrt(d1r.astype(np.float32)))) == 167
+    # the matches describe one homography: RANSAC keeps nearly all of them
+    obj = np.c_[kr["x"][good], kr["y"][good]]
+    scene = np.c_[kl["x"][i1[good]], kl["y"][i1[good]]]
+    H, mask, info = oracle.find_homography(obj, scene)
+    assert info["found"] and info["inliers"] >= 160
