@@ -246,7 +246,7 @@ def main():
             del d_t, d_q, d_o
 
         # ---- CPU oracle on a bounded sample of the same workload ----------------
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is reported at N = 1 only
             from oracle import oracle as O
             cores = min(16, os.cpu_count() or 1)
             tcpu = time.perf_counter()
