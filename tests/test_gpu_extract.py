@@ -222,3 +222,15 @@ def test_single_image_call_grows_its_workspace(ctx, oracle, lenna_bgr):
         assert np.array_equal(kps, kps2) and np.array_equal(desc, desc2)
     finally:
         ctx.set_single_image_capacity(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["school_left.jpg", "school_right.jpg"])
+def test_natural_800x600_photographs(sift_lib, ctx, oracle, name):
+    """The reference's panorama example frames (res/school_*.jpg): natural content, large flat and saturated areas."""
+    from conftest import _load_rgb
+    gray = oracle.bgr_to_gray(_load_rgb(name)[:, :, ::-1].copy())
+    kp, desc, o = run_both(sift_lib, ctx, oracle, gray, check_pyramid=False)
+    assert len(kp) == {"school_left.jpg": 2686, "school_right.jpg": 3472}[name]
+    assert np.array_equal(desc, o.descriptors().astype(desc.dtype))
+    assert np.array_equal(kp["angle"], o.keypoints()["angle"])
