@@ -210,6 +210,21 @@ typedef struct sift_homography_info {
 int sift_find_homography(sift_ctx *ctx, const float *src_xy, const float *dst_xy, int n, double reproj_threshold,
                          int max_iters, double confidence, double H[9], uint8_t *mask, sift_homography_info *info);
 
+/* ---- panorama composition ------------------------------------------------------ */
+/* Images are 8-bit BGR on the host, `stride` bytes per row; outputs are tightly packed.
+ *
+ * cv::warpPerspective(src, dst, H, Size(dw, dh)) as main.cpp:115 calls it: INTER_LINEAR,
+ * BORDER_CONSTANT black, H maps src to dst.  SIFT_ERR_INVALID when H is singular. */
+int sift_warp_perspective_bgr8(sift_ctx *ctx, const uint8_t *src, int sw, int sh, size_t stride, const double H[9], int dw,
+                               int dh, uint8_t *dst);
+/* main.cpp:115-145: warp `ref` by H into a canvas of ref_w + img_w columns and ref_h rows, take `img` where a
+ * channel of the canvas is zero, blend 0.7 img + 0.3 canvas over img's rectangle, and drop as many columns from
+ * the right as there are all-black columns.  out must hold ref_h * (ref_w + img_w) * 3 bytes; its rows are packed
+ * at the cropped width *out_w.  SIFT_ERR_INVALID when img is taller than ref (the reference throws) or H is
+ * singular. */
+int sift_stitch_pair_bgr8(sift_ctx *ctx, const uint8_t *ref, int ref_w, int ref_h, size_t ref_stride, const uint8_t *img,
+                          int img_w, int img_h, size_t img_stride, const double H[9], uint8_t *out, int *out_w);
+
 /* ---- synthetic inputs (host) ---------------------------------------------- */
 /* Dead-leaves frame generator: splitmix64 seeded with
  * seed*0x9E3779B97F4A7C15 + frame_index; w*h/128 discs painted over a 128-gray

@@ -25,7 +25,7 @@ STATS_DTYPE = np.dtype([(f, "<i8") for f in STATS_FIELDS])
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("sift_oracle.c", "homography_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("sift_oracle.c", "homography_oracle.c", "stitch_oracle.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libsift_oracle.so"])
     return _LIB_PATH
@@ -274,3 +274,28 @@ def homography_inliers(src, dst, H, thresh=3.0):
     n = lib().orc_h_inliers(C.c_void_p(src.ctypes.data), C.c_void_p(dst.ctypes.data), src.shape[0], C.c_void_p(H.ctypes.data),
                             C.c_double(thresh), C.c_void_p(mask.ctypes.data))
     return n, mask[:src.shape[0]]
+
+
+# ---- panorama composition restatement (stitch_oracle.c; parity unpinned) ----
+
+def warp_perspective(src_bgr, H, dw, dh):
+    src = np.ascontiguousarray(src_bgr, np.uint8)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    dst = np.zeros((dh, dw, 3), np.uint8)
+    ok = lib().orc_warp_perspective(C.c_void_p(src.ctypes.data), src.shape[1], src.shape[0], C.c_void_p(H.ctypes.data), dw, dh,
+                                    C.c_void_p(dst.ctypes.data))
+    return dst if ok else None
+
+
+def stitch_pair(ref_bgr, img_bgr, H):
+    """main.cpp:115-145: returns the cropped panorama (rows of ref, up to ref+img columns) or None."""
+    ref = np.ascontiguousarray(ref_bgr, np.uint8)
+    img = np.ascontiguousarray(img_bgr, np.uint8)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    out = np.zeros(ref.shape[0] * (ref.shape[1] + img.shape[1]) * 3, np.uint8)
+    w = C.c_int()
+    ok = lib().orc_stitch_pair(C.c_void_p(ref.ctypes.data), ref.shape[1], ref.shape[0], C.c_void_p(img.ctypes.data), img.shape[1],
+                               img.shape[0], C.c_void_p(H.ctypes.data), C.c_void_p(out.ctypes.data), C.byref(w))
+    if not ok:
+        return None
+    return out[: ref.shape[0] * w.value * 3].reshape(ref.shape[0], w.value, 3).copy()

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "sift_batch_counts", "sift_batch_download", "sift_batch_result_device_ptrs", "sift_batch_get_level",
     "sift_batch_get_candidates", "sift_batch_get_oriented", "sift_batch_run_profiled", "sift_knn2_u8",
     "sift_knn2_f32", "sift_knn2_device", "sift_knn2_merge_device", "sift_match_min_dist_filter",
-    "sift_find_homography",
+    "sift_find_homography", "sift_warp_perspective_bgr8", "sift_stitch_pair_bgr8",
     "sift_synth_dead_leaves", "sift_synth_descriptors", "sift_synth_queries",
 )
 
@@ -136,6 +136,8 @@ def lib():
     L.sift_knn2_device.argtypes = [vp, vp, ci, vp, ci, ci, vp]
     L.sift_knn2_merge_device.argtypes = [vp, vp, ci, ci, vp, vp]
     L.sift_match_min_dist_filter.argtypes = [vp, ci, vp, C.POINTER(C.c_int32)]
+    L.sift_warp_perspective_bgr8.argtypes = [vp, vp, ci, ci, sz, vp, ci, ci, vp]
+    L.sift_stitch_pair_bgr8.argtypes = [vp, vp, ci, ci, sz, vp, ci, ci, sz, vp, vp, C.POINTER(ci)]
     L.sift_find_homography.argtypes = [vp, vp, vp, ci, C.c_double, ci, C.c_double, vp, vp, C.POINTER(_HomographyInfo)]
     L.sift_synth_dead_leaves.argtypes = [u64, u64, ci, ci, vp]
     L.sift_synth_descriptors.argtypes = [u64, i64, vp]
@@ -282,6 +284,26 @@ class Context:
                                           confidence, H.ctypes.data, mask.ctypes.data, C.byref(info)))
         d = {k: getattr(info, k) for k, _ in _HomographyInfo._fields_}
         return (H.reshape(3, 3) if info.found else None), mask[:n], d
+
+    def warp_perspective(self, src_bgr, H, dw, dh):
+        """warpPerspective(src, dst, H, Size(dw, dh)) (main.cpp:115): HxWx3 uint8 -> dh x dw x 3."""
+        src = np.ascontiguousarray(src_bgr, np.uint8)
+        H = np.ascontiguousarray(H, np.float64).reshape(9)
+        dst = np.zeros((dh, dw, 3), np.uint8)
+        _check(lib().sift_warp_perspective_bgr8(self._h, src.ctypes.data, src.shape[1], src.shape[0], src.strides[0],
+                                                H.ctypes.data, dw, dh, dst.ctypes.data))
+        return dst
+
+    def stitch_pair(self, ref_bgr, img_bgr, H):
+        """main.cpp:115-145: the cropped panorama of `ref` warped by H and `img`."""
+        ref = np.ascontiguousarray(ref_bgr, np.uint8)
+        img = np.ascontiguousarray(img_bgr, np.uint8)
+        H = np.ascontiguousarray(H, np.float64).reshape(9)
+        out = np.zeros(ref.shape[0] * (ref.shape[1] + img.shape[1]) * 3, np.uint8)
+        w = C.c_int()
+        _check(lib().sift_stitch_pair_bgr8(self._h, ref.ctypes.data, ref.shape[1], ref.shape[0], ref.strides[0], img.ctypes.data,
+                                           img.shape[1], img.shape[0], img.strides[0], H.ctypes.data, out.ctypes.data, C.byref(w)))
+        return out[: ref.shape[0] * w.value * 3].reshape(ref.shape[0], w.value, 3).copy()
 
     def knn2_device(self, d_q, nq, d_t, nt, train_base, d_out):
         _check(lib().sift_knn2_device(self._h, d_q, nq, d_t, nt, train_base, d_out))

@@ -45,4 +45,10 @@ hipError_t find_homography_ransac(hipStream_t st, void *workspace, const float *
                                   double threshold, int max_iters, double confidence, double H[9], uint8_t *mask,
                                   sift_homography_info *info);
 
+// kernels_stitch.hip
+bool invert3x3(const double S[9], double D[9]);
+void launch_warp_perspective(hipStream_t st, const uint8_t *src, int sw, int sh, const double Minv[9], int dw, int dh, uint8_t *dst);
+void launch_fill_and_blend(hipStream_t st, uint8_t *canvas, int cw, const uint8_t *img, int iw, int ih);
+void launch_column_grey_sums(hipStream_t st, const uint8_t *canvas, int cw, int ch, int *sums);
+
 }  // namespace sa

@@ -75,6 +75,8 @@ struct sift_ctx {
     size_t knn_io_bytes = 0;
     void *h_work = nullptr;  // device workspace of sift_find_homography
     size_t h_work_bytes = 0;
+    void *st_work = nullptr;  // device workspace of the composition calls
+    size_t st_work_bytes = 0;
     sift_batch *cached = nullptr;  // workspace of the single-image calls
     int single_cap = 0;            // its initial per-frame list capacity (0: the batch default)
 };
@@ -142,6 +144,7 @@ int sift_ctx_destroy(sift_ctx *ctx) {
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
     if (ctx->knn_io) hipFree(ctx->knn_io);
     if (ctx->h_work) hipFree(ctx->h_work);
+    if (ctx->st_work) hipFree(ctx->st_work);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SIFT_OK;
@@ -737,6 +740,66 @@ int sift_find_homography(sift_ctx *ctx, const float *src_xy, const float *dst_xy
     HIP_TRY(find_homography_ransac(ctx->stream, ctx->h_work, src_xy, dst_xy, n, reproj_threshold, max_iters, confidence, H,
                                    mask, info ? info : &local));
     return SIFT_OK;
+}
+
+// ---- panorama composition ---------------------------------------------------------
+
+static int stitch_common(sift_ctx *ctx, const uint8_t *ref, int rw, int rh, size_t rstride, const uint8_t *img, int iw, int ih,
+                         size_t istride, const double H[9], int dw, int dh, uint8_t *out, int *out_w) {
+    if (!ctx || !ref || !H || !out) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (rw < 1 || rh < 1 || dw < 1 || dh < 1 || rstride < (size_t)rw * 3) return fail(SIFT_ERR_INVALID, "bad image size");
+    if ((int64_t)dw * dh > (int64_t)1 << 28 || (int64_t)rw * rh > (int64_t)1 << 28) return fail(SIFT_ERR_INVALID, "image too large");
+    if (img && (iw < 1 || ih < 1 || istride < (size_t)iw * 3)) return fail(SIFT_ERR_INVALID, "bad image size");
+    if (img && ih > rh) return fail(SIFT_ERR_INVALID, "the new image is taller than the panorama");
+    double Minv[9];
+    if (!invert3x3(H, Minv)) return fail(SIFT_ERR_INVALID, "singular homography");
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t ref_b = up((size_t)rw * rh * 3), img_b = img ? up((size_t)iw * ih * 3) : 0, can_b = up((size_t)dw * dh * 3);
+    const size_t need = ref_b + img_b + can_b + up((size_t)dw * sizeof(int));
+    if (need > ctx->st_work_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc = ensure_bytes(&ctx->st_work, &ctx->st_work_bytes, need);
+        if (rc) return rc;
+    }
+    hipStream_t st = ctx->stream;
+    uint8_t *d_ref = (uint8_t *)ctx->st_work, *d_img = d_ref + ref_b, *d_can = d_img + img_b;
+    int *d_sums = (int *)(d_can + can_b);
+    HIP_TRY(hipMemcpy2DAsync(d_ref, (size_t)rw * 3, ref, rstride, (size_t)rw * 3, rh, hipMemcpyHostToDevice, st));
+    launch_warp_perspective(st, d_ref, rw, rh, Minv, dw, dh, d_can);
+    if (!img) {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, d_can, (size_t)dw * dh * 3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return SIFT_OK;
+    }
+    HIP_TRY(hipMemcpy2DAsync(d_img, (size_t)iw * 3, img, istride, (size_t)iw * 3, ih, hipMemcpyHostToDevice, st));
+    launch_fill_and_blend(st, d_can, dw, d_img, iw, ih);
+    launch_column_grey_sums(st, d_can, dw, dh, d_sums);
+    HIP_TRY(hipGetLastError());
+    std::vector<int> sums((size_t)dw);
+    HIP_TRY(hipMemcpyAsync(sums.data(), d_sums, (size_t)dw * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int remove_cols = 0;
+    for (int s : sums) remove_cols += s == 0;  // main.cpp:141: every all-black column counts, wherever it lies
+    const int nw = dw - remove_cols;
+    if (nw > 0)
+        HIP_TRY(hipMemcpy2DAsync(out, (size_t)nw * 3, d_can, (size_t)dw * 3, (size_t)nw * 3, dh, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *out_w = nw;
+    return SIFT_OK;
+}
+
+int sift_warp_perspective_bgr8(sift_ctx *ctx, const uint8_t *src, int sw, int sh, size_t stride, const double H[9], int dw,
+                               int dh, uint8_t *dst) {
+    return stitch_common(ctx, src, sw, sh, stride, nullptr, 0, 0, 0, H, dw, dh, dst, nullptr);
+}
+
+int sift_stitch_pair_bgr8(sift_ctx *ctx, const uint8_t *ref, int ref_w, int ref_h, size_t ref_stride, const uint8_t *img,
+                          int img_w, int img_h, size_t img_stride, const double H[9], uint8_t *out, int *out_w) {
+    if (!img || !out_w) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (ref_w < 1 || img_w < 1 || (int64_t)ref_w + img_w > INT32_MAX) return fail(SIFT_ERR_INVALID, "bad image size");
+    return stitch_common(ctx, ref, ref_w, ref_h, ref_stride, img, img_w, img_h, img_stride, H, ref_w + img_w, ref_h, out, out_w);
 }
 
 }  // extern "C"

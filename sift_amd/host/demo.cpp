@@ -1,7 +1,8 @@
-// Counterpart of the reference's src/main.cpp up to the homography
-// (main.cpp:22-105): extract features of every image, then match the last image
-// (the reference) against each of the others, report the good matches and
-// estimate the homography that maps the reference onto the image.
+// Counterpart of the reference's src/main.cpp (main.cpp:22-152), without the match
+// drawing: extract features of every image, then, from the last image backwards,
+// match the running panorama against the next image, report the good matches,
+// estimate the homography that maps the panorama onto the image, compose the
+// two ("Final-<names>.png") and carry the result on as the new panorama.
 // Images are PNG or binary PGM/PPM files, read by sift_io::imread with the
 // conventions of cv::imread (BGR, 8-bit, 3 channels).
 //
@@ -42,17 +43,18 @@ int main(int argc, char **argv) {
         printf("No image data \n");
         return -1;
     }
-    const std::string name_ref = stem_of(argv[argc - 1]);
-    sift::sift_handler s_ref(name_ref, ref.clone());
-    s_ref.exec();
-    cv::Mat ref_descriptors = s_ref.get();
+    std::string name_ref = stem_of(argv[argc - 1]);
     for (int k = argc - 2; k >= 1; k--) {
+        sift::sift_handler s_ref(name_ref, ref.clone());  // main.cpp:56-60: the panorama so far is extracted again
+        s_ref.exec();
+        cv::Mat ref_descriptors = s_ref.get();
         cv::Mat img = sift_io::imread(argv[k]);
         if (!img.data) {
             printf("No image data - %s \n", argv[k]);
             return -1;
         }
-        sift::sift_handler s(stem_of(argv[k]), std::move(img));
+        const std::string name = stem_of(argv[k]);
+        sift::sift_handler s(name, img.clone());
         s.exec();
         cv::Mat desc = s.get();
         auto matches = sift::knn_match(ref_descriptors, desc);  // query = ref, train = img (main.cpp:75)
@@ -73,6 +75,16 @@ int main(int argc, char **argv) {
             for (int r = 0; r < 3; r++) std::cout << "H " << hr.H[3 * r] << " " << hr.H[3 * r + 1] << " " << hr.H[3 * r + 2] << std::endl;
             std::cout.precision(6);
         }
+        name_ref += '+' + name;  // main.cpp:108
+        if (!hr.found || img.rows > ref.rows) {
+            std::cout << "no panorama for " << name_ref << std::endl;  // the reference throws here
+            return 1;
+        }
+        cv::Mat result = sift::stitch_pair(ref, img, hr.H);  // main.cpp:115-145
+        std::cerr << result.size() << "\n";                   // main.cpp:147
+        if (!sift_io::imwrite("./Final-" + name_ref + ".png", result)) return 1;  // main.cpp:149
+        std::cout << "panorama " << result.cols << " " << result.rows << std::endl;
+        ref = std::move(result);  // main.cpp:151
     }
     return 0;
 }

@@ -171,6 +171,49 @@ cv::Mat decode_png(const unsigned char *data, std::size_t size, std::string *err
     return m;
 }
 
+bool imwrite(const std::string &path, const cv::Mat &bgr) {
+    if (bgr.empty() || bgr.type() != CV_8UC3) return false;
+    const std::size_t w = (std::size_t)bgr.cols, h = (std::size_t)bgr.rows;
+    std::vector<unsigned char> raw((w * 3 + 1) * h);
+    for (std::size_t y = 0; y < h; y++) {
+        unsigned char *line = raw.data() + (w * 3 + 1) * y;
+        const unsigned char *src = bgr.ptr<unsigned char>((int)y);
+        *line++ = 0;  // filter type: none
+        for (std::size_t x = 0; x < w; x++) {
+            line[3 * x] = src[3 * x + 2];
+            line[3 * x + 1] = src[3 * x + 1];
+            line[3 * x + 2] = src[3 * x];
+        }
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), Z_DEFAULT_COMPRESSION) != Z_OK) return false;
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    auto put32 = [](unsigned char *p, uint32_t v) { p[0] = (unsigned char)(v >> 24), p[1] = (unsigned char)(v >> 16), p[2] = (unsigned char)(v >> 8), p[3] = (unsigned char)v; };
+    auto chunk = [&](const char *tag, const unsigned char *body, std::size_t n) {
+        unsigned char head[8], tail[4];
+        put32(head, (uint32_t)n);
+        std::memcpy(head + 4, tag, 4);
+        uLong crc = crc32(0L, head + 4, 4);
+        if (n) crc = crc32(crc, body, (uInt)n);
+        put32(tail, (uint32_t)crc);
+        f.write(reinterpret_cast<const char *>(head), 8);
+        if (n) f.write(reinterpret_cast<const char *>(body), (std::streamsize)n);
+        f.write(reinterpret_cast<const char *>(tail), 4);
+    };
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    f.write(reinterpret_cast<const char *>(sig), 8);
+    unsigned char ihdr[13];
+    put32(ihdr, (uint32_t)w);
+    put32(ihdr + 4, (uint32_t)h);
+    ihdr[8] = 8, ihdr[9] = 2, ihdr[10] = 0, ihdr[11] = 0, ihdr[12] = 0;  // 8-bit RGB, no interlace
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), zlen);
+    chunk("IEND", nullptr, 0);
+    return (bool)f;
+}
+
 cv::Mat imread(const std::string &path) {
     std::ifstream f(path, std::ios::binary);
     if (!f) return cv::Mat();

@@ -183,4 +183,30 @@ homography_result find_homography(const std::vector<cv::Point2f> &obj, const std
     return r;
 }
 
+static void require_bgr8(const cv::Mat &m, const char *what) {
+    if (m.empty() || m.type() != CV_8UC3) throw std::runtime_error(std::string(what) + ": expected a non-empty CV_8UC3 image");
+}
+
+cv::Mat stitch_pair(const cv::Mat &ref, const cv::Mat &img, const double H[9]) {
+    require_bgr8(ref, "stitch_pair");
+    require_bgr8(img, "stitch_pair");
+    std::vector<unsigned char> buf((size_t)ref.rows * ((size_t)ref.cols + img.cols) * 3);
+    int w = 0;
+    check(sift_stitch_pair_bgr8(context(), ref.data, ref.cols, ref.rows, ref.step, img.data, img.cols, img.rows, img.step, H,
+                                buf.data(), &w),
+          "sift_stitch_pair_bgr8");
+    cv::Mat out(ref.rows, w, CV_8UC3);
+    for (int r = 0; r < ref.rows && w > 0; r++) std::memcpy(out.ptr<unsigned char>(r), buf.data() + (size_t)r * w * 3, (size_t)w * 3);
+    return out;
+}
+
+cv::Mat warp_perspective(const cv::Mat &src, const double H[9], cv::Size dsize) {
+    require_bgr8(src, "warp_perspective");
+    cv::Mat out(dsize.height, dsize.width, CV_8UC3);
+    if (out.step != (size_t)dsize.width * 3) throw std::runtime_error("warp_perspective: unexpected row padding");
+    check(sift_warp_perspective_bgr8(context(), src.data, src.cols, src.rows, src.step, H, dsize.width, dsize.height, out.data),
+          "sift_warp_perspective_bgr8");
+    return out;
+}
+
 }  // namespace sift

@@ -89,6 +89,14 @@ struct homography_result {
 homography_result find_homography(const std::vector<cv::Point2f> &obj, const std::vector<cv::Point2f> &scene,
                                   double ransacReprojThreshold = 3, int maxIters = 2000, double confidence = 0.995);
 
+// The composition step of main.cpp:115-145 for 8-bit BGR images: `ref` warped by H (3x3 row-major, as
+// find_homography returns it) into a canvas of ref.cols + img.cols columns, holes filled from `img`, the 0.7 / 0.3
+// blend over img's rectangle, cropped by the number of all-black columns.  img must not be taller than ref (the
+// reference throws there).
+cv::Mat stitch_pair(const cv::Mat &ref, const cv::Mat &img, const double H[9]);
+// cv::warpPerspective(src, dst, H, dsize) with the defaults main.cpp:115 uses (bilinear, black border).
+cv::Mat warp_perspective(const cv::Mat &src, const double H[9], cv::Size dsize);
+
 }  // namespace sift
 
 #endif
