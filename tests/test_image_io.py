@@ -28,6 +28,7 @@ def checker(tmp_path_factory):
     def run(*paths):
         out = subprocess.run([exe, *map(str, paths)], check=True, capture_output=True, text=True).stdout
         return [line.split()[1:] for line in out.strip().splitlines()]
+    run.exe = exe
     return run
 
 
@@ -199,3 +200,17 @@ def test_broken_and_unsupported_jpegs_yield_empty(checker, tmp_path):
     (tmp_path / "cut.jpg").write_bytes(good[:len(good) * 2 // 3])
     g = checker(tmp_path / "cut.jpg")[0]
     assert g[:2] == as_list(JPEG_EXPECTED["generated"]["base_420.jpg"])[:2]
+
+
+def test_imwrite_png_round_trip(checker, tmp_path, lenna_bgr):
+    """sift_io::imwrite (cv::imwrite at main.cpp:149): the PNG it writes decodes, with Pillow and with
+    sift_io::imread, to the pixels it was given."""
+    from PIL import Image
+    out = tmp_path / "copy.png"
+    subprocess.check_call([checker.exe, "--copy", os.path.join(GOLDEN, "Lenna.png"), str(out)])
+    assert np.array_equal(np.array(Image.open(out).convert("RGB"))[:, :, ::-1], lenna_bgr)
+    assert checker(out)[0] == expect(lenna_bgr)
+    odd = tmp_path / "odd.png"
+    subprocess.check_call([checker.exe, "--copy", os.path.join(JPEG_DIR, "tiny_3x5.jpg"), str(odd)])
+    assert checker(odd)[0] == as_list(JPEG_EXPECTED["generated"]["tiny_3x5.jpg"])
+    assert subprocess.call([checker.exe, "--copy", str(tmp_path / "missing.png"), str(tmp_path / "x.png")]) == 1
