@@ -97,6 +97,15 @@ def test_ragged_sizes(sift_lib, ctx, oracle, w, h, seed):
     run_both(sift_lib, ctx, oracle, sift_lib.synth_dead_leaves(seed, 0, w, h))
 
 
+@pytest.mark.parametrize("w,h,seed", [(2, 2, 31), (3, 7, 32), (8, 8, 33), (5, 300, 34), (300, 5, 35), (2, 64, 36), (17, 2, 37),
+                                      (40, 23, 38)])
+def test_tiny_and_sliver_frames(sift_lib, ctx, oracle, w, h, seed):
+    """The smallest frames the octave rule allows (sift.cpp:36) and extreme aspect ratios: every blur radius
+    exceeds the image, so rows and columns are reflected several times over; pyramid and DoG must still be
+    bit-identical, and nothing may be read out of bounds."""
+    run_both(sift_lib, ctx, oracle, sift_lib.synth_dead_leaves(seed, 0, w, h))
+
+
 def test_natural_crop_non_multiple_of_tile(sift_lib, ctx, oracle, lenna_bgr):
     gray = oracle.bgr_to_gray(lenna_bgr)[37:37 + 301, 50:50 + 415].copy()
     run_both(sift_lib, ctx, oracle, gray)
