@@ -144,3 +144,51 @@ def test_demo_writes_the_school_panorama(sift_lib, oracle, tmp_path):
     want = oracle.stitch_pair(_load_rgb("school_right.jpg")[:, :, ::-1].copy(), _load_rgb("school_left.jpg")[:, :, ::-1].copy(), H)
     assert np.array_equal(pano, want)
     assert "[%d x %d]" % (want.shape[1], want.shape[0]) in out.stderr
+
+
+def oracle_main(oracle, images, names):
+    """The reference's main.cpp:41-152 with the CPU oracle: returns {file name: panorama}."""
+    ref, name_ref = images[-1], names[-1]
+    out = {}
+    for k in range(len(images) - 2, -1, -1):
+        o_ref = oracle.OracleSift(oracle.bgr_to_gray(ref)).exec(threads=8, blur_threads=8)
+        o_img = oracle.OracleSift(oracle.bgr_to_gray(images[k])).exec(threads=8, blur_threads=8)
+        kq, dq, kt, dt = o_ref.keypoints(), o_ref.descriptors(), o_img.keypoints(), o_img.descriptors()
+        i1, d1, *_ = oracle.knn2_u8(dq.astype(np.uint8), dt.astype(np.uint8), threads=8)
+        good = oracle.min_dist_filter(np.sqrt(d1.astype(np.float32)))
+        obj = np.c_[kq["x"][good], kq["y"][good]].astype(np.float32)
+        scene = np.c_[kt["x"][i1[good]], kt["y"][i1[good]]].astype(np.float32)
+        H, mask, info = oracle.find_homography(obj, scene)
+        name_ref += "+" + names[k]
+        assert H is not None, name_ref
+        ref = oracle.stitch_pair(ref, images[k], H)
+        out["Final-%s.png" % name_ref] = ref
+    return out
+
+
+@pytest.mark.gpu
+def test_demo_chains_three_images_like_main(sift_lib, oracle, tmp_path):
+    """Three overlapping views of one synthetic scene, each with its own sensor noise, given as
+    `smai a.png b.png c.png`: the panorama grows from the last image backwards (main.cpp:54-151) and every
+    Final-*.png equals what the CPU restatements of all stages produce."""
+    from PIL import Image
+    import test_cpp_dropin
+    test_cpp_dropin.build_host(sift_lib)
+    scene = sift_lib.synth_dead_leaves(77, 0, 900, 360)
+    rng = np.random.default_rng(5)
+    names, images = ["a", "b", "c"], []
+    for n, x0 in zip(names, (0, 190, 380)):
+        view = scene[:, x0:x0 + 420].astype(np.int16) + rng.integers(-3, 4, (360, 420))
+        g = np.clip(view, 0, 255).astype(np.uint8)
+        bgr = np.stack([g, g, g], axis=2)
+        images.append(bgr)
+        Image.fromarray(bgr).save(tmp_path / (n + ".png"))
+    want = oracle_main(oracle, images, names)
+    out = subprocess.run([os.path.join(HOST, "sift_demo")] + [str(tmp_path / (n + ".png")) for n in names], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert sorted(want) == ["Final-c+b+a.png", "Final-c+b.png"]
+    for fname, pano in want.items():
+        got = np.array(Image.open(tmp_path / fname).convert("RGB"))[:, :, ::-1]
+        assert got.shape == pano.shape and np.array_equal(got, pano), fname
+    assert want["Final-c+b+a.png"].shape[1] > want["Final-c+b.png"].shape[1] > 420
