@@ -77,6 +77,8 @@ struct sift_ctx {
     size_t h_work_bytes = 0;
     void *st_work = nullptr;  // device workspace of the composition calls
     size_t st_work_bytes = 0;
+    void *pinned = nullptr;  // page-locked host staging of the single-image calls and of result downloads
+    size_t pinned_bytes = 0;
     sift_batch *cached = nullptr;  // workspace of the single-image calls
     int single_cap = 0;            // its initial per-frame list capacity (0: the batch default)
 };
@@ -102,6 +104,22 @@ struct sift_batch {
     int lvl_ntaps[IMAGES]{};
     std::vector<hipEvent_t> events;
 };
+
+// Page-locked staging: copies between pageable user memory and the device go through it, because the runtime
+// otherwise pins and unpins the user's pages on every call (milliseconds for a frame or a descriptor block).
+// The stream must be idle when it is (re)used.
+static int ensure_pinned(sift_ctx *ctx, size_t want) {
+    if (ctx->pinned_bytes >= want) return SIFT_OK;
+    if (ctx->pinned) {
+        hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    HIP_TRY(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+    return SIFT_OK;
+}
 
 extern "C" {
 
@@ -145,6 +163,7 @@ int sift_ctx_destroy(sift_ctx *ctx) {
     if (ctx->knn_io) hipFree(ctx->knn_io);
     if (ctx->h_work) hipFree(ctx->h_work);
     if (ctx->st_work) hipFree(ctx->st_work);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SIFT_OK;
@@ -449,25 +468,28 @@ int sift_batch_download(sift_batch *b, int frame, int capacity, sift_keypoint *k
     if (n_out) *n_out = n;
     if (n > capacity) return fail(SIFT_ERR_INVALID, "capacity smaller than the frame's keypoint count");
     if (n == 0) return SIFT_OK;
+    // one staged transfer: keypoints, then descriptors, into page-locked memory; converted from there
+    const size_t kp_bytes = keypoints ? (size_t)n * sizeof(DevKeypoint) : 0;
+    const size_t kp_span = (kp_bytes + 255) & ~(size_t)255;
+    const size_t desc_bytes = (desc_u8 || desc_f64) ? (size_t)n * 128 : 0;
+    int rc = ensure_pinned(b->ctx, kp_span + desc_bytes);
+    if (rc) return rc;
+    char *stage = static_cast<char *>(b->ctx->pinned);
+    if (kp_bytes)
+        HIP_TRY(hipMemcpyAsync(stage, b->d_final + (size_t)frame * b->kp_cap, kp_bytes, hipMemcpyDeviceToHost, st));
+    if (desc_bytes)
+        HIP_TRY(hipMemcpyAsync(stage + kp_span, b->d_desc + (size_t)frame * b->kp_cap * 128, desc_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (keypoints) {
-        std::vector<DevKeypoint> tmp((size_t)n);
-        HIP_TRY(hipMemcpyAsync(tmp.data(), b->d_final + (size_t)frame * b->kp_cap, (size_t)n * sizeof(DevKeypoint),
-                               hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (int i = 0; i < n; i++) std::memcpy(&keypoints[i], &tmp[i], sizeof(sift_keypoint));
+        static_assert(sizeof(DevKeypoint) >= sizeof(sift_keypoint), "device record holds the public fields first");
+        const DevKeypoint *src = reinterpret_cast<const DevKeypoint *>(stage);
+        for (int i = 0; i < n; i++) std::memcpy(&keypoints[i], &src[i], sizeof(sift_keypoint));
     }
-    if (desc_u8 || desc_f64) {
-        std::vector<uint8_t> tmp;
-        uint8_t *dst = desc_u8;
-        if (!dst) {
-            tmp.resize((size_t)n * 128);
-            dst = tmp.data();
-        }
-        HIP_TRY(hipMemcpyAsync(dst, b->d_desc + (size_t)frame * b->kp_cap * 128, (size_t)n * 128,
-                               hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+    if (desc_bytes) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(stage + kp_span);
+        if (desc_u8) std::memcpy(desc_u8, src, desc_bytes);
         if (desc_f64)
-            for (size_t i = 0; i < (size_t)n * 128; i++) desc_f64[i] = (double)dst[i];
+            for (size_t i = 0; i < desc_bytes; i++) desc_f64[i] = (double)src[i];
     }
     return SIFT_OK;
 }
@@ -552,8 +574,21 @@ static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_
             if (rc) return rc;
             ctx->cached = b;
         }
-        int rc = bgr ? sift_batch_upload_bgr8(b, 0, img, stride) : sift_batch_upload_gray8(b, 0, img, stride);
+        // the frame goes up through page-locked staging (the stream is idle between single-image calls)
+        const size_t row_bytes = (size_t)w * (bgr ? 3 : 1);
+        if (stride < row_bytes) return fail(SIFT_ERR_INVALID, "stride smaller than a row");
+        int rc = ensure_pinned(ctx, row_bytes * h);
         if (rc) return rc;
+        for (int y = 0; y < h; y++) std::memcpy(static_cast<char *>(ctx->pinned) + row_bytes * y, img + stride * y, row_bytes);
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (bgr) {
+            if (!b->d_bgr) HIP_TRY(hipMalloc((void **)&b->d_bgr, row_bytes * h));
+            HIP_TRY(hipMemcpyAsync(b->d_bgr, ctx->pinned, row_bytes * h, hipMemcpyHostToDevice, ctx->stream));
+            launch_bgr_to_gray(ctx->stream, b->d_bgr, b->d_frames, (size_t)w * h);
+            HIP_TRY(hipGetLastError());
+        } else {
+            HIP_TRY(hipMemcpyAsync(b->d_frames, ctx->pinned, row_bytes * h, hipMemcpyHostToDevice, ctx->stream));
+        }
         if ((rc = sift_batch_run(b, 1))) return rc;
         rc = sift_batch_counts(b, 1, &fc);
         if (rc == SIFT_ERR_OVERFLOW && attempt < 4) {
