@@ -289,7 +289,7 @@ class Context:
         """warpPerspective(src, dst, H, Size(dw, dh)) (main.cpp:115): HxWx3 uint8 -> dh x dw x 3."""
         src = np.ascontiguousarray(src_bgr, np.uint8)
         H = np.ascontiguousarray(H, np.float64).reshape(9)
-        dst = np.zeros((dh, dw, 3), np.uint8)
+        dst = np.empty((dh, dw, 3), np.uint8)
         _check(lib().sift_warp_perspective_bgr8(self._h, src.ctypes.data, src.shape[1], src.shape[0], src.strides[0],
                                                 H.ctypes.data, dw, dh, dst.ctypes.data))
         return dst
@@ -299,7 +299,7 @@ class Context:
         ref = np.ascontiguousarray(ref_bgr, np.uint8)
         img = np.ascontiguousarray(img_bgr, np.uint8)
         H = np.ascontiguousarray(H, np.float64).reshape(9)
-        out = np.zeros(ref.shape[0] * (ref.shape[1] + img.shape[1]) * 3, np.uint8)
+        out = np.empty(ref.shape[0] * (ref.shape[1] + img.shape[1]) * 3, np.uint8)
         w = C.c_int()
         _check(lib().sift_stitch_pair_bgr8(self._h, ref.ctypes.data, ref.shape[1], ref.shape[0], ref.strides[0], img.ctypes.data,
                                            img.shape[1], img.shape[0], img.strides[0], H.ctypes.data, out.ctypes.data, C.byref(w)))

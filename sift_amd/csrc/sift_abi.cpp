@@ -800,27 +800,36 @@ static int stitch_common(sift_ctx *ctx, const uint8_t *ref, int rw, int rh, size
     hipStream_t st = ctx->stream;
     uint8_t *d_ref = (uint8_t *)ctx->st_work, *d_img = d_ref + ref_b, *d_can = d_img + img_b;
     int *d_sums = (int *)(d_can + can_b);
-    HIP_TRY(hipMemcpy2DAsync(d_ref, (size_t)rw * 3, ref, rstride, (size_t)rw * 3, rh, hipMemcpyHostToDevice, st));
+    // images and the canvas cross PCIe through the context's page-locked staging buffer
+    HIP_TRY(hipStreamSynchronize(st));
+    {
+        int rc = ensure_pinned(ctx, ref_b + img_b + can_b);
+        if (rc) return rc;
+    }
+    uint8_t *h_ref = static_cast<uint8_t *>(ctx->pinned), *h_img = h_ref + ref_b, *h_can = h_img + img_b;
+    for (int y = 0; y < rh; y++) std::memcpy(h_ref + (size_t)y * rw * 3, ref + rstride * y, (size_t)rw * 3);
+    HIP_TRY(hipMemcpyAsync(d_ref, h_ref, (size_t)rw * rh * 3, hipMemcpyHostToDevice, st));
     launch_warp_perspective(st, d_ref, rw, rh, Minv, dw, dh, d_can);
     if (!img) {
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out, d_can, (size_t)dw * dh * 3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_can, d_can, (size_t)dw * dh * 3, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(out, h_can, (size_t)dw * dh * 3);
         return SIFT_OK;
     }
-    HIP_TRY(hipMemcpy2DAsync(d_img, (size_t)iw * 3, img, istride, (size_t)iw * 3, ih, hipMemcpyHostToDevice, st));
+    for (int y = 0; y < ih; y++) std::memcpy(h_img + (size_t)y * iw * 3, img + istride * y, (size_t)iw * 3);
+    HIP_TRY(hipMemcpyAsync(d_img, h_img, (size_t)iw * ih * 3, hipMemcpyHostToDevice, st));
     launch_fill_and_blend(st, d_can, dw, d_img, iw, ih);
     launch_column_grey_sums(st, d_can, dw, dh, d_sums);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_can, d_can, (size_t)dw * dh * 3, hipMemcpyDeviceToHost, st));
     std::vector<int> sums((size_t)dw);
     HIP_TRY(hipMemcpyAsync(sums.data(), d_sums, (size_t)dw * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     int remove_cols = 0;
     for (int s : sums) remove_cols += s == 0;  // main.cpp:141: every all-black column counts, wherever it lies
     const int nw = dw - remove_cols;
-    if (nw > 0)
-        HIP_TRY(hipMemcpy2DAsync(out, (size_t)nw * 3, d_can, (size_t)dw * 3, (size_t)nw * 3, dh, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    for (int y = 0; y < dh && nw > 0; y++) std::memcpy(out + (size_t)y * nw * 3, h_can + (size_t)y * dw * 3, (size_t)nw * 3);
     *out_w = nw;
     return SIFT_OK;
 }
