@@ -121,6 +121,16 @@ static int ensure_pinned(sift_ctx *ctx, size_t want) {
     return SIFT_OK;
 }
 
+// Staging for a host-to-device copy: waits until the stream has drained (so that nothing still reads the buffer),
+// then hands out `bytes` of page-locked memory.
+static int stage_in(sift_ctx *ctx, size_t bytes, void **out) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int rc = ensure_pinned(ctx, bytes);
+    if (rc) return rc;
+    *out = ctx->pinned;
+    return SIFT_OK;
+}
+
 extern "C" {
 
 const char *sift_last_error(void) { return g_last_error.c_str(); }
@@ -331,7 +341,11 @@ int sift_batch_upload_gray8(sift_batch *b, int frame, const uint8_t *gray, size_
     if (stride < (size_t)b->w) return fail(SIFT_ERR_INVALID, "stride smaller than width");
     HIP_TRY(hipSetDevice(b->ctx->device));
     uint8_t *dst = b->d_frames + (size_t)frame * b->w * b->h;
-    HIP_TRY(hipMemcpy2DAsync(dst, b->w, gray, stride, b->w, b->h, hipMemcpyHostToDevice, b->ctx->stream));
+    void *stage = nullptr;
+    int rc = stage_in(b->ctx, (size_t)b->w * b->h, &stage);
+    if (rc) return rc;
+    for (int y = 0; y < b->h; y++) std::memcpy(static_cast<char *>(stage) + (size_t)y * b->w, gray + stride * y, (size_t)b->w);
+    HIP_TRY(hipMemcpyAsync(dst, stage, (size_t)b->w * b->h, hipMemcpyHostToDevice, b->ctx->stream));
     return SIFT_OK;
 }
 
@@ -342,12 +356,13 @@ int sift_batch_upload_bgr8(sift_batch *b, int frame, const uint8_t *bgr, size_t 
     HIP_TRY(hipSetDevice(b->ctx->device));
     const size_t px = (size_t)b->w * b->h;
     if (!b->d_bgr) HIP_TRY(hipMalloc((void **)&b->d_bgr, px * 3));
-    HIP_TRY(hipMemcpy2DAsync(b->d_bgr, (size_t)b->w * 3, bgr, stride, (size_t)b->w * 3, b->h, hipMemcpyHostToDevice,
-                             b->ctx->stream));
+    void *stage = nullptr;
+    int rc = stage_in(b->ctx, px * 3, &stage);  // waits for the stream: the device-side BGR buffer is free again too
+    if (rc) return rc;
+    for (int y = 0; y < b->h; y++) std::memcpy(static_cast<char *>(stage) + (size_t)y * b->w * 3, bgr + stride * y, (size_t)b->w * 3);
+    HIP_TRY(hipMemcpyAsync(b->d_bgr, stage, px * 3, hipMemcpyHostToDevice, b->ctx->stream));
     launch_bgr_to_gray(b->ctx->stream, b->d_bgr, b->d_frames + (size_t)frame * px, px);
     HIP_TRY(hipGetLastError());
-    // the staging buffer is reused by the next upload
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     return SIFT_OK;
 }
 
@@ -513,8 +528,12 @@ int sift_batch_get_level(sift_batch *b, int frame, int oct, int lvl, int kind, d
     const size_t plane = (size_t)b->pyr.w[oct] * b->pyr.h[oct];
     const double *src = kind == SIFT_LEVEL_GAUSS ? b->pyr.gauss[oct] + gauss_off(b->pyr, oct, frame, lvl)
                                                  : b->pyr.dog[oct] + dog_off(b->pyr, oct, frame, lvl);
-    HIP_TRY(hipMemcpyAsync(out, src, plane * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    void *stage = nullptr;
+    int rc = stage_in(b->ctx, plane * sizeof(double), &stage);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stage, src, plane * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    std::memcpy(out, stage, plane * sizeof(double));
     return SIFT_OK;
 }
 
@@ -574,13 +593,14 @@ static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_
             if (rc) return rc;
             ctx->cached = b;
         }
-        // the frame goes up through page-locked staging (the stream is idle between single-image calls)
+        // the frame goes up through page-locked staging
         const size_t row_bytes = (size_t)w * (bgr ? 3 : 1);
         if (stride < row_bytes) return fail(SIFT_ERR_INVALID, "stride smaller than a row");
-        int rc = ensure_pinned(ctx, row_bytes * h);
-        if (rc) return rc;
-        for (int y = 0; y < h; y++) std::memcpy(static_cast<char *>(ctx->pinned) + row_bytes * y, img + stride * y, row_bytes);
         HIP_TRY(hipSetDevice(ctx->device));
+        void *stage = nullptr;
+        int rc = stage_in(ctx, row_bytes * h, &stage);
+        if (rc) return rc;
+        for (int y = 0; y < h; y++) std::memcpy(static_cast<char *>(stage) + row_bytes * y, img + stride * y, row_bytes);
         if (bgr) {
             if (!b->d_bgr) HIP_TRY(hipMalloc((void **)&b->d_bgr, row_bytes * h));
             HIP_TRY(hipMemcpyAsync(b->d_bgr, ctx->pinned, row_bytes * h, hipMemcpyHostToDevice, ctx->stream));

@@ -67,7 +67,8 @@ class Mat {
         cols = c;
         type_ = type;
         step = (size_t)c * elemSize();
-        store_ = std::shared_ptr<unsigned char>(new unsigned char[step * (size_t)(r > 0 ? r : 1)](),
+        // contents are indeterminate, as with cv::Mat::create
+        store_ = std::shared_ptr<unsigned char>(new unsigned char[step * (size_t)(r > 0 ? r : 1)],
                                                std::default_delete<unsigned char[]>());
         data = store_.get();
     }

@@ -32,6 +32,23 @@ sift_ctx *context() {
     return ctx;
 }
 
+// The pyramid workspace of the last frame size, kept between exec() calls (allocating and freeing it costs more
+// than running a frame through it).  The library is used from one thread at a time, as the reference is.
+// `min_capacity` (keypoints per frame, 0 = the library's default) only ever grows the workspace.
+sift_batch *workspace(int w, int h, int min_capacity) {
+    static sift_batch *batch = nullptr;
+    static int bw = 0, bh = 0, cap = 0;
+    if (!batch || bw != w || bh != h || cap < min_capacity) {
+        if (batch) sift_batch_destroy(batch);
+        batch = nullptr;
+        check(sift_batch_create(context(), w, h, 1, min_capacity, &batch), "sift_batch_create");
+        bw = w;
+        bh = h;
+        cap = min_capacity;
+    }
+    return batch;
+}
+
 }  // namespace
 
 // sift.cpp:26-46: gray conversion, onex, octave count; the 2x upsample and base
@@ -72,13 +89,24 @@ sift_handler::~sift_handler() {
 // sift.cpp:67-98
 void sift_handler::exec() {
     std::cerr << "Running SIFT for " << name << "\n";
-    sift_ctx *ctx = context();
     sift_batch *batch = nullptr;
-    check(sift_batch_create(ctx, width_, height_, 1, 0, &batch), "sift_batch_create");
-    try {
+    sift_stage_times t;
+    sift_frame_counts counts;
+    // keypoints and descriptors are unbounded vectors in the reference (sift.hpp:93-94): a frame that overflows
+    // the workspace is run again in a larger one
+    for (int capacity = 0, attempt = 0;; attempt++) {
+        batch = workspace(width_, height_, capacity);
         check(sift_batch_upload_gray8(batch, 0, gray_.data(), (size_t)width_), "sift_batch_upload_gray8");
-        sift_stage_times t;
         check(sift_batch_run_profiled(batch, 1, &t), "sift_batch_run_profiled");
+        const int rc = sift_batch_counts(batch, 1, &counts);
+        if (rc == SIFT_ERR_OVERFLOW && attempt < 4) {
+            capacity = 2 * std::max({counts.candidates, counts.oriented, 8192, width_ * height_ / 16});
+            continue;
+        }
+        check(rc, "sift_batch_counts");
+        break;
+    }
+    {
         // the reference's five TIMEIT stages (sift.cpp:71,72,86,87,92); the DoG
         // subtraction is fused into the blur launches, so its own time is zero
         const double blur = t.ms[SIFT_STAGE_BLUR_L1] + t.ms[SIFT_STAGE_BLUR_L2] + t.ms[SIFT_STAGE_BLUR_L3] +
@@ -90,8 +118,6 @@ void sift_handler::exec() {
         std::cerr << "elapsed time: clean_keypoints: " << 1e-3 * t.ms[SIFT_STAGE_CLEAN] << "s\n";
         std::cerr << "elapsed time: get_descriptors: " << 1e-3 * t.ms[SIFT_STAGE_DESCRIPTOR] << "s\n";
 
-        sift_frame_counts counts;
-        check(sift_batch_counts(batch, 1, &counts), "sift_batch_counts");
         const int n = counts.keypoints;
         std::vector<sift_keypoint> kps((size_t)n);
         std::vector<double> desc((size_t)n * 128);
@@ -106,11 +132,7 @@ void sift_handler::exec() {
         }
         base = cv::Mat(2 * height_, 2 * width_, CV_64FC1);  // sift.cpp:45
         check(sift_batch_get_level(batch, 0, 0, 0, SIFT_LEVEL_GAUSS, base.ptr<double>(0)), "sift_batch_get_level");
-    } catch (...) {
-        sift_batch_destroy(batch);
-        throw;
     }
-    sift_batch_destroy(batch);
     std::cerr << "Keypoints Calculated: " << keypoints.size() << "\n";
     dump_keypoints();
     std::cerr << "Completed SIFT for " << name << "\n\n";
@@ -128,7 +150,8 @@ cv::Mat sift_handler::get() const {
 void sift_handler::dump_keypoints() {
     std::ofstream fout;
     fout.open(this->name + ".csv", std::ios::out);
-    for (auto &kpt : this->keypoints) fout << kpt.pt.x << "," << kpt.pt.y << "," << kpt.size << "," << kpt.angle << std::endl;
+    // same bytes as the reference's per-line std::endl, written with one flush at the end
+    for (auto &kpt : this->keypoints) fout << kpt.pt.x << "," << kpt.pt.y << "," << kpt.size << "," << kpt.angle << "\n";
     fout.close();
 }
 
