@@ -101,7 +101,9 @@ int sift_batch_destroy(sift_batch *b);
 /* Device pointer of the 8-bit gray frame buffer, [max_frames][h][w], for
  * callers that fill frames on the GPU themselves. */
 int sift_batch_frames_device_ptr(sift_batch *b, void **dptr);
-/* Copy one host frame into slot `frame` (asynchronous on the context stream). */
+/* Copy one host frame into slot `frame`.  The call waits for earlier work on the context stream, copies the
+ * frame into the context's page-locked staging buffer (the caller's buffer may be reused on return) and enqueues the
+ * transfer on the stream. */
 int sift_batch_upload_gray8(sift_batch *b, int frame, const uint8_t *gray, size_t stride);
 int sift_batch_upload_bgr8(sift_batch *b, int frame, const uint8_t *bgr, size_t stride);
 /* Make the next runs read their frames from a caller-owned device buffer laid
