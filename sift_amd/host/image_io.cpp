@@ -96,6 +96,7 @@ cv::Mat decode_png(const unsigned char *data, std::size_t size, std::string *err
         pos += 12 + (std::size_t)len;
     }
     if (ctype < 0 || w == 0 || h == 0 || w > (1u << 20) || h > (1u << 20)) return fail(error, "bad header");
+    if ((uint64_t)w * h > (1ull << 28)) return fail(error, "image too large");
     if (interlace) return fail(error, "interlaced PNG is not supported");
     int channels;
     switch (ctype) {

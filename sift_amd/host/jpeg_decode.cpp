@@ -238,6 +238,7 @@ struct Decoder {
         width = s[3] << 8 | s[4];
         ncomp = s[5];
         if (width <= 0 || height <= 0) return fail("bad dimensions");
+        if ((long long)width * height > (1LL << 28)) return fail("image too large");
         if (ncomp != 1 && ncomp != 3) return fail("only grey and three-component files are supported");
         if (n < 6 + 3 * (size_t)ncomp) return fail("truncated frame header");
         progressive = prog;
@@ -352,7 +353,7 @@ struct Decoder {
 
         auto decode_block = [&](Component &c, short *b) {
             if (!progressive) {
-                const int t = br.decode(dc[c.dc_tbl]);
+                const int t = std::min(br.decode(dc[c.dc_tbl]), 16);  // a larger category only occurs in corrupt data
                 c.pred += t ? extend(br.get(t), t) : 0;
                 b[0] = (short)c.pred;
                 const HuffTable &h = ac[c.ac_tbl];
@@ -369,7 +370,7 @@ struct Decoder {
                 }
             } else if (Ss == 0) {
                 if (Ah == 0) {
-                    const int t = br.decode(dc[c.dc_tbl]);
+                    const int t = std::min(br.decode(dc[c.dc_tbl]), 16);  // a larger category only occurs in corrupt data
                     c.pred += t ? extend(br.get(t), t) : 0;
                     b[0] = (short)(c.pred * (1 << Al));
                 } else if (br.get(1)) {

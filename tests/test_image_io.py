@@ -214,3 +214,44 @@ def test_imwrite_png_round_trip(checker, tmp_path, lenna_bgr):
     subprocess.check_call([checker.exe, "--copy", os.path.join(JPEG_DIR, "tiny_3x5.jpg"), str(odd)])
     assert checker(odd)[0] == as_list(JPEG_EXPECTED["generated"]["tiny_3x5.jpg"])
     assert subprocess.call([checker.exe, "--copy", str(tmp_path / "missing.png"), str(tmp_path / "x.png")]) == 1
+
+
+def test_mutated_files_do_not_break_the_decoders(tmp_path):
+    """400 corrupted copies of the JPEG fixtures and of a PNG (random byte edits in headers and entropy data,
+    truncations, absurd dimensions) through the decoders built with AddressSanitizer and UBSan: any result is
+    acceptable, an out-of-bounds access or undefined operation is not."""
+    import random
+    exe = str(tmp_path / "image_io_check_asan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++20", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I" + HOST, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "image_io_check.cpp"),
+                           os.path.join(HOST, "image_io.cpp"), os.path.join(HOST, "jpeg_decode.cpp"), "-lz", "-o", exe])
+    rnd = random.Random(2024)
+    sources = sorted(glob.glob(os.path.join(JPEG_DIR, "*.jpg")))
+    png = open(os.path.join(GOLDEN, "Lenna.png"), "rb").read()[:20000]
+    paths = []
+    for k in range(400):
+        if k % 8 == 7:
+            b, ext = bytearray(png), ".png"
+            for _ in range(rnd.randint(1, 6)):
+                b[rnd.randrange(8, len(b) if rnd.random() < 0.5 else 60)] = rnd.randrange(256)
+        else:
+            b, ext = bytearray(open(rnd.choice(sources), "rb").read()), ".jpg"
+            sos, mode = b.find(b"\xff\xda"), rnd.random()
+            if mode < 0.4:
+                for _ in range(rnd.randint(1, 4)):
+                    b[rnd.randrange(2, sos + 14)] = rnd.randrange(256)
+            elif mode < 0.7:
+                for _ in range(rnd.randint(1, 30)):
+                    b[rnd.randrange(sos, len(b))] = rnd.choice([0xFF, 0x00, rnd.randrange(256)])
+            elif mode < 0.85:
+                b = b[:rnd.randrange(2, len(b))]
+            else:
+                i = max(b.find(b"\xff\xc0"), b.find(b"\xff\xc2"))
+                b[i + 5:i + 9] = struct.pack(">HH", rnd.choice([0, 1, 9, 65535, rnd.randrange(65536)]),
+                                             rnd.choice([0, 1, 9, 65535, rnd.randrange(65536)]))
+        p = tmp_path / ("m%03d%s" % (k, ext))
+        p.write_bytes(bytes(b))
+        paths.append(str(p))
+    for i in range(0, len(paths), 100):
+        r = subprocess.run([exe] + paths[i:i + 100], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
