@@ -212,3 +212,19 @@ def test_gpu_homography_from_extracted_features(ctx, oracle, sift_lib):
     H, mask, info = assert_same(ctx, oracle, obj, scene)
     assert H is not None and info["inliers"] >= 20
     assert np.allclose(H, [[1, 0, -40], [0, 1, -24], [0, 0, 1]], atol=0.2)  # inliers lie within 3 px
+
+
+@pytest.mark.gpu
+def test_gpu_homography_with_non_finite_points(ctx, oracle):
+    """NaN and infinite coordinates (a caller's bug) must neither hang nor disturb the finite correspondences:
+    models drawn through them score no inliers on either side."""
+    src, dst = make_case(41, 300, 0.3)
+    src[5] = (np.nan, 10.0)
+    dst[17] = (np.inf, -np.inf)
+    src[200] = (np.inf, np.nan)
+    H, mask, info = assert_same(ctx, oracle, src, dst)
+    assert H is not None and np.isfinite(H).all() and info["inliers"] > 150
+    assert not mask[[5, 17, 200]].any()
+    bad = np.full((20, 2), np.nan, np.float32)
+    H, mask, info = assert_same(ctx, oracle, bad, bad)
+    assert H is None
