@@ -243,3 +243,26 @@ def test_natural_800x600_photographs(sift_lib, ctx, oracle, name):
     assert len(kp) == {"school_left.jpg": 2686, "school_right.jpg": 3472}[name]
     assert np.array_equal(desc, o.descriptors().astype(desc.dtype))
     assert np.array_equal(kp["angle"], o.keypoints()["angle"])
+
+
+def _patterns():
+    yy, xx = np.mgrid[0:150, 0:210]
+    rng = np.random.default_rng(3)
+    return {
+        "checkerboard8": (((yy // 8 + xx // 8) & 1) * 255).astype(np.uint8),
+        "checkerboard1": (((yy + xx) & 1) * 255).astype(np.uint8),
+        "stripes": ((xx // 5 & 1) * 200 + 20).astype(np.uint8),
+        "one_pixel": np.where((yy == 70) & (xx == 100), 255, 0).astype(np.uint8),
+        "white": np.full((150, 210), 255, np.uint8),
+        "ramp": ((xx + yy) % 256).astype(np.uint8),
+        "binary_noise": (rng.integers(0, 2, (150, 210)) * 255).astype(np.uint8),
+        "discs": np.where(((yy - 75) ** 2 + (xx - 105) ** 2 < 40 ** 2) ^ ((yy - 60) ** 2 + (xx - 90) ** 2 < 12 ** 2), 230, 25).astype(np.uint8),
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_patterns()))
+def test_regular_and_degenerate_patterns(sift_lib, ctx, oracle, name):
+    """Periodic patterns produce exactly repeated values (ties in the non-strict extremum test and in the sort
+    keys), saturated and constant frames produce none: everything must still agree with the oracle."""
+    run_both(sift_lib, ctx, oracle, _patterns()[name])
