@@ -27,9 +27,23 @@
 #define SIFT_AMD_HAVE_OPENCV 0
 #endif
 
+#include <chrono>
 #include <cstdint>
+#include <iostream>
 #include <string>
 #include <vector>
+
+// The reference's header also hands its users a stopwatch macro (sift.hpp:11-18): TIMEIT(f) calls f() and
+// reports "elapsed time: f: <seconds>s" on stderr.
+#ifndef TIMEIT
+#define TIMEIT(f)                                                                                          \
+    do {                                                                                                   \
+        const auto timeit_begin_ = std::chrono::steady_clock::now();                                       \
+        f();                                                                                               \
+        const std::chrono::duration<double> timeit_span_ = std::chrono::steady_clock::now() - timeit_begin_; \
+        std::cerr << "elapsed time: " << #f << ": " << timeit_span_.count() << "s\n";                      \
+    } while (0)
+#endif
 
 namespace sift {
 

@@ -40,7 +40,14 @@ def test_class_surface_compiles_like_main_cpp(sift_lib, tmp_path):
                 auto d = ss.get();
                 auto k = ss.keypoints;
                 (void)d; (void)k;
+                // the homography and composition calls that stand in for main.cpp:105 and :115-145
+                std::vector<cv::Point2f> obj, scene;
+                auto hr = sift::find_homography(obj, scene, 3);
+                cv::Mat pano = sift::stitch_pair(image, image, hr.H);
+                (void)pano;
             }
+            auto nothing = [] {};
+            TIMEIT(nothing);                                                           // sift.hpp:11-18
             return 0;
         }
     """))
@@ -48,6 +55,8 @@ def test_class_surface_compiles_like_main_cpp(sift_lib, tmp_path):
     subprocess.check_call(["g++", "-std=c++20", "-I" + HOST, "-I" + os.path.join(ROOT, "include"), str(src),
                            "-o", str(exe), "-L" + HOST, "-lsift_handler", "-L" + os.path.join(ROOT, "sift_amd"),
                            "-lsift_amd", "-Wl,-rpath," + HOST, "-Wl,-rpath," + os.path.join(ROOT, "sift_amd")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stderr.startswith("elapsed time: nothing: ") and out.stderr.rstrip().endswith("s")
 
 
 def write_ppm(path, bgr):
