@@ -48,6 +48,20 @@ __device__ __forceinline__ double neighbour_lane(double v) {
 // neighbours from the adjacent lanes, so there is no LDS staging and no barrier.
 constexpr int EX_TW = 62, EX_TH = 16;
 
+// max / min of finite doubles as the bare instruction.  fmax()/fmin() make the compiler quieten possible
+// signalling NaNs first (one extra v_max_f64 per operand that comes from memory or from a lane exchange),
+// which nearly doubled the instruction count of the scan; the difference-of-Gaussian values are finite.
+__device__ __forceinline__ double max_finite(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double min_finite(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
                                                   FrameCounters *__restrict__ counters) {
     const int w = p.w[oct], h = p.h[oct];
@@ -83,13 +97,13 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
         for (int r = 0; r < RY + 2; r++) {
             const double b = v[lvl][r];
             const double a = neighbour_lane<true>(b), c = neighbour_lane<false>(b);
-            hmax[r] = fmax(fmax(a, b), c);
-            hmin[r] = fmin(fmin(a, b), c);
+            hmax[r] = max_finite(max_finite(a, b), c);
+            hmin[r] = min_finite(min_finite(a, b), c);
         }
 #pragma unroll
         for (int q = 0; q < RY; q++) {
-            vmax[lvl % 3][q] = fmax(fmax(hmax[q], hmax[q + 1]), hmax[q + 2]);
-            vmin[lvl % 3][q] = fmin(fmin(hmin[q], hmin[q + 1]), hmin[q + 2]);
+            vmax[lvl % 3][q] = max_finite(max_finite(hmax[q], hmax[q + 1]), hmax[q + 2]);
+            vmin[lvl % 3][q] = min_finite(min_finite(hmin[q], hmin[q + 1]), hmin[q + 2]);
         }
         if (lvl >= 2) {
             const int img = lvl - 1;  // levels img-1, img, img+1 are in the window
@@ -97,8 +111,8 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
             for (int q = 0; q < RY; q++) {
                 const int i = i0 + q;
                 const double c = v[img][q + 1];
-                const double hi = fmax(fmax(vmax[0][q], vmax[1][q]), vmax[2][q]);
-                const double lo = fmin(fmin(vmin[0][q], vmin[1][q]), vmin[2][q]);
+                const double hi = max_finite(max_finite(vmax[0][q], vmax[1][q]), vmax[2][q]);
+                const double lo = min_finite(min_finite(vmin[0][q], vmin[1][q]), vmin[2][q]);
                 const bool is_ext =
                     column_tested && i < h - BORDER && fabs(c) > threshold && (c > 0 ? c >= hi : c <= lo);  // sift.cpp:268
                 const int slot = wave_append(is_ext, &counters[f].candidates);
