@@ -1,0 +1,44 @@
+"""The bench line: the last recorded run (profiles/r1_bench.json, written by `python bench.py` on an MI355X)
+carries every field the measurement contract names, with consistent values."""
+import json
+import os
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def load(name):
+    lines = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()
+    return json.loads(lines[-1])
+
+
+def test_recorded_bench_line_has_the_contract_fields():
+    d = load("r1_bench.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "frames/s"
+    for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    frames = d["config"]["frames_per_gpu_per_step"] * d["steps"] * d["n_gpus"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.5
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+
+
+def test_rocprof_summary_agrees_with_the_event_timing():
+    """profiles/r1_bench_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of the run that wrote
+    r1_bench_profiled.json: the dominant kernel's average duration must match the HIP-event figure."""
+    import csv
+    d = load("r1_bench_profiled.json")
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_bench_kernel_stats.csv"))))
+    name = d["roofline"]["kernel"].split()[0]   # k_blur_march<13>
+    hit = [r for r in rows if name in r["Name"]]
+    assert len(hit) == 1
+    avg_ms = float(hit[0]["AverageNs"]) * 1e-6
+    assert abs(avg_ms - d["roofline"]["avg_launch_ms"]) / avg_ms < 0.05
