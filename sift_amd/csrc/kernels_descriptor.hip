@@ -131,6 +131,16 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                     if (hi >= lo - 2) {
                         my_jlo = max(jmin, (int)floor(lo) - 1);
                         my_jhi = min(jmax, (int)ceil(hi) + 1);
+                        // Tighten the estimate to the exact set { j : -1 < bin_row, bin_col < 4 } (sift.cpp:503), with
+                        // the expressions the samples use.  Each of the four conditions is monotone in j (products and
+                        // sums round monotonically), so the set is an interval and the sample loop needs no test.
+                        auto inside = [&](int j) {
+                            const double dj = (double)j;
+                            const double br = su * dj + my_Bu, bc = sv * dj + my_Bv;
+                            return br > -1 && bc > -1 && br < WINDOW_WIDTH && bc < WINDOW_WIDTH;
+                        };
+                        while (my_jlo <= my_jhi && !inside(my_jlo)) my_jlo++;
+                        while (my_jhi >= my_jlo && !inside(my_jhi)) my_jhi--;
                     }
                     my_wi = use_tab ? sm.wtab[min(abs(i), 255)] : exp(wscale * (double)(i * i));
                 }
@@ -175,7 +185,6 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                         const double dj = (double)j;
                         const double bin_row = su * dj + Bu[r];
                         const double bin_col = sv * dj + Bv[r];
-                        if (!(bin_row > -1 && bin_col > -1 && bin_row < WINDOW_WIDTH && bin_col < WINDOW_WIDTH)) continue;
                         // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) (sift.cpp:512-517) as a product of two table entries
                         // a zero gradient adds +0.0 to eight bins, which leaves every one of them unchanged
                         if (g[r].mag == 0.0) continue;
