@@ -77,6 +77,9 @@ struct sift_ctx {
     size_t h_work_bytes = 0;
     void *st_work = nullptr;  // device workspace of the composition calls
     size_t st_work_bytes = 0;
+    hipStream_t aux = nullptr;              // second stream of the small-workload schedule (run_pipeline)
+    hipEvent_t oct_ready[MAX_OCTAVES] = {};  // level 3 of octave o is complete
+    hipEvent_t aux_done = nullptr;
     void *pinned = nullptr;  // page-locked host staging of the single-image calls and of result downloads
     size_t pinned_bytes = 0;
     sift_batch *cached = nullptr;  // workspace of the single-image calls
@@ -174,6 +177,10 @@ int sift_ctx_destroy(sift_ctx *ctx) {
     if (ctx->h_work) hipFree(ctx->h_work);
     if (ctx->st_work) hipFree(ctx->st_work);
     if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->aux) hipStreamDestroy(ctx->aux);
+    for (hipEvent_t e : ctx->oct_ready)
+        if (e) hipEventDestroy(e);
+    if (ctx->aux_done) hipEventDestroy(ctx->aux_done);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SIFT_OK;
@@ -408,14 +415,40 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
         if (tm.end()) return fail(SIFT_ERR_HIP, "hipEventRecord");      \
     } while (0)
     const uint8_t *frames = b->d_ext_frames ? b->d_ext_frames : b->d_frames;
-    TIMED(SIFT_STAGE_BASE, launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
-    for (int o = 0; o < b->pyr.octaves; o++)
-        for (int lvl = 1; lvl < IMAGES; lvl++)
-            TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
-    for (int o = 0; o < b->pyr.octaves; o++)
-        if (b->pyr.grad[o]) TIMED(SIFT_STAGE_GRADIENT, launch_gradients(st, b->pyr, o, n));
-    for (int o = 0; o < b->pyr.octaves; o++)
-        TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
+    // A workload that does not fill the chip (a single frame, a few small ones) is bound by the latency of its
+    // ~70 dependent launches.  Only levels 1-3 of an octave feed the next octave, so the main stream runs base and
+    // levels 1-3 octave after octave while a second stream takes levels 4-5, the gradient planes and the extrema scan
+    // of each finished octave: about half as many launches on the critical path.  Large batches keep the plain order
+    // (their launches fill the chip, and the profiled pass times each launch on its own).
+    const bool two_streams = !times && (int64_t)n * b->w * b->h <= ((int64_t)1 << 22);
+    if (two_streams) {
+        if (!ctx->aux) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->oct_ready) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->aux_done, hipEventDisableTiming));
+        }
+        hipStream_t aux = ctx->aux;
+        launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps);
+        for (int o = 0; o < b->pyr.octaves; o++) {
+            for (int lvl = 1; lvl <= IMAGES - 3; lvl++) launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
+            HIP_TRY(hipEventRecord(ctx->oct_ready[o], st));
+            HIP_TRY(hipStreamWaitEvent(aux, ctx->oct_ready[o], 0));
+            for (int lvl = IMAGES - 2; lvl < IMAGES; lvl++) launch_blur_dog(aux, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
+            if (b->pyr.grad[o]) launch_gradients(aux, b->pyr, o, n);
+            launch_extrema(aux, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters);
+        }
+        HIP_TRY(hipEventRecord(ctx->aux_done, aux));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_done, 0));
+    } else {
+        TIMED(SIFT_STAGE_BASE, launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
+        for (int o = 0; o < b->pyr.octaves; o++)
+            for (int lvl = 1; lvl < IMAGES; lvl++)
+                TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
+        for (int o = 0; o < b->pyr.octaves; o++)
+            if (b->pyr.grad[o]) TIMED(SIFT_STAGE_GRADIENT, launch_gradients(st, b->pyr, o, n));
+        for (int o = 0; o < b->pyr.octaves; o++)
+            TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
+    }
     TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_sorted, b->d_oriented,
                                                       b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames));
     TIMED(SIFT_STAGE_CLEAN,
