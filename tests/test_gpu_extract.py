@@ -266,3 +266,27 @@ def test_regular_and_degenerate_patterns(sift_lib, ctx, oracle, name):
     """Periodic patterns produce exactly repeated values (ties in the non-strict extremum test and in the sort
     keys), saturated and constant frames produce none: everything must still agree with the oracle."""
     run_both(sift_lib, ctx, oracle, _patterns()[name])
+
+
+@pytest.mark.gpu
+def test_repeated_small_runs_are_identical(sift_lib, ctx):
+    """Small workloads are scheduled on two streams; 150 back-to-back runs of frames of different sizes must
+    give the same keypoints and descriptors every time (a missing dependency would show as a flicker)."""
+    frames = [sift_lib.synth_dead_leaves(50 + k, 0, w, h) for k, (w, h) in enumerate(((320, 240), (512, 512), (97, 131)))]
+    want = [ctx.extract(f)[:2] for f in frames]
+    for it in range(150):
+        k = it % len(frames)
+        kp, desc, _ = ctx.extract(frames[k])
+        assert np.array_equal(kp, want[k][0]) and np.array_equal(desc, want[k][1]), (it, k)
+    b = ctx.batch(320, 240, 3)
+    try:
+        for i in range(3):
+            b.upload(i, frames[0])
+        for it in range(50):
+            b.run(3)
+            b.counts(3)
+            for i in range(3):
+                kp, desc = b.download(i)
+                assert np.array_equal(kp, want[0][0]) and np.array_equal(desc.astype(np.float64), want[0][1]), (it, i)
+    finally:
+        b.close()
