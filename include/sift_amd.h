@@ -180,11 +180,21 @@ int sift_knn2_f32(sift_ctx *ctx, const float *q, int nq, const float *t, int nt,
  * whose indices are offset by train_index_base (for a train shard). */
 int sift_knn2_device(sift_ctx *ctx, const void *d_q, int nq, const void *d_t, int nt, int train_index_base,
                      void *d_out);
+/* sift_knn2_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same results;
+ * the train biases and per-split partial results live in a 16 MiB array that is part of the library's code object
+ * (every GPU the library is used on holds its own copy until the process ends) instead of a buffer the context
+ * allocates on demand, and the call makes no hipMalloc/hipFree.  Limit: nt <= SIFT_KNN2_NOALLOC_MAX_TRAIN train rows
+ * per call, any nq (shard a larger train set with train_index_base and merge with sift_knn2_merge_device); beyond it
+ * the call fails with SIFT_ERR_INVALID and enqueues nothing.  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU (two contexts, two streams) race; calls on one context are ordered by its stream. */
+#define SIFT_KNN2_NOALLOC_MAX_TRAIN 2097152
+int sift_knn2_device_noalloc(sift_ctx *ctx, const void *d_q, int nq, const void *d_t, int nt, int train_index_base,
+                             void *d_out);
 /* Merge `nparts` partial results per query (d_parts laid out [nparts][nq]) into
  * d_out[nq] ordered by (distance, index), and apply the ratio test into
  * d_accept[nq] (may be NULL).  Device pointers, asynchronous. */
 int sift_knn2_merge_device(sift_ctx *ctx, const void *d_parts, int nparts, int nq, void *d_out, void *d_accept);
-/* Bytes of scratch sift_knn2_device needs (train norms); allocated once per context on demand. */
 
 /* The live filter of main.cpp:77-91 on 1-NN results: min_dist starts at 100,
  * a query is good when sqrtf(d1) < 3*min_dist.  Host only.  Returns the number

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "sift_batch_frames_device_ptr", "sift_batch_set_external_frames", "sift_batch_upload_gray8", "sift_batch_upload_bgr8", "sift_batch_run",
     "sift_batch_counts", "sift_batch_download", "sift_batch_result_device_ptrs", "sift_batch_get_level",
     "sift_batch_get_candidates", "sift_batch_get_oriented", "sift_batch_run_profiled", "sift_knn2_u8",
-    "sift_knn2_f32", "sift_knn2_device", "sift_knn2_merge_device", "sift_match_min_dist_filter",
+    "sift_knn2_f32", "sift_knn2_device", "sift_knn2_device_noalloc", "sift_knn2_merge_device", "sift_match_min_dist_filter",
     "sift_find_homography", "sift_warp_perspective_bgr8", "sift_stitch_pair_bgr8",
     "sift_synth_dead_leaves", "sift_synth_descriptors", "sift_synth_queries",
 )
@@ -134,6 +134,7 @@ def lib():
     L.sift_knn2_u8.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     L.sift_knn2_f32.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     L.sift_knn2_device.argtypes = [vp, vp, ci, vp, ci, ci, vp]
+    L.sift_knn2_device_noalloc.argtypes = [vp, vp, ci, vp, ci, ci, vp]
     L.sift_knn2_merge_device.argtypes = [vp, vp, ci, ci, vp, vp]
     L.sift_match_min_dist_filter.argtypes = [vp, ci, vp, C.POINTER(C.c_int32)]
     L.sift_warp_perspective_bgr8.argtypes = [vp, vp, ci, ci, sz, vp, ci, ci, vp]
@@ -307,6 +308,10 @@ class Context:
 
     def knn2_device(self, d_q, nq, d_t, nt, train_base, d_out):
         _check(lib().sift_knn2_device(self._h, d_q, nq, d_t, nt, train_base, d_out))
+
+    def knn2_device_noalloc(self, d_q, nq, d_t, nt, train_base, d_out):
+        """sift_knn2_device on the library's static scratch: no device allocation; nt <= 2,097,152."""
+        _check(lib().sift_knn2_device_noalloc(self._h, d_q, nq, d_t, nt, train_base, d_out))
 
     def knn2_merge_device(self, d_parts, nparts, nq, d_out, d_accept):
         _check(lib().sift_knn2_merge_device(self._h, d_parts, nparts, nq, d_out, d_accept))

@@ -21,12 +21,22 @@
 // take the exact update path.  Ties resolve to the smaller train index.
 #include <limits.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "kernels.h"
+
+// Scratch of the entry point that allocates nothing (sift_knn2_device_noalloc): train biases and the
+// per-split partial results live here instead of in a hipMalloc'ed buffer.  Every GPU the library
+// runs on holds its own copy of the array, at its own address, until the process ends.  The name is
+// only a host-side handle: host code uses the address hipGetSymbolAddress reports for the current
+// device (knn_static_scratch below), never the name itself.
+static __device__ __align__(256) unsigned char scratch[sa::KNN_STATIC_SCRATCH_BYTES];
 
 namespace sa {
 
 namespace {
+
 
 using v4i = __attribute__((ext_vector_type(4))) int;
 using v16i = __attribute__((ext_vector_type(16))) int;
@@ -285,10 +295,30 @@ int choose_splits(int nq, int nt) {
 
 }  // namespace
 
+// Device address of `scratch` on `device` (which must be the current device), resolved once per device.
+hipError_t knn_static_scratch(int device, void **ptr) {
+    constexpr int MAX_DEVICES = 64;
+    static std::mutex mu;
+    static void *resolved[MAX_DEVICES] = {};
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!resolved[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        resolved[device] = p;
+    }
+    *ptr = resolved[device];
+    return hipSuccess;
+}
+
+// Train biases, then one partial result row per train split (none when the launch has a single split:
+// it writes the caller's output directly).
 size_t knn_scratch_bytes(int nq, int nt) {
     const int splits = choose_splits(nq, nt);
     size_t bias = ((size_t)nt * sizeof(int) + 255) & ~(size_t)255;
-    return bias + (size_t)splits * nq * sizeof(sift_knn2);
+    return bias + (splits > 1 ? (size_t)splits * nq * sizeof(sift_knn2) : 0);
 }
 
 void launch_knn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int train_base, sift_knn2 *out,

@@ -71,6 +71,7 @@ struct sift_ctx {
     hipStream_t stream = nullptr;
     void *knn_scratch = nullptr;
     size_t knn_scratch_bytes = 0;
+    void *knn_static = nullptr;  // this device's copy of the matcher's file-scope scratch array (sift_knn2_device_noalloc)
     void *knn_io = nullptr;  // device staging of the host-buffer matcher calls
     size_t knn_io_bytes = 0;
     void *h_work = nullptr;  // device workspace of sift_find_homography
@@ -162,6 +163,13 @@ int sift_ctx_create(int device, sift_ctx **out) {
         hipStreamDestroy(c->stream);
         delete c;
         return fail(SIFT_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    }
+    // address of the matcher's static scratch array on this device (the device is current here)
+    e = knn_static_scratch(device, &c->knn_static);
+    if (e != hipSuccess) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return fail(SIFT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
     }
     *out = c;
     return SIFT_OK;
@@ -726,6 +734,27 @@ int sift_knn2_device(sift_ctx *ctx, const void *d_q, int nq, const void *d_t, in
     }
     launch_knn2(ctx->stream, (const uint8_t *)d_q, nq, (const uint8_t *)d_t, nt, train_index_base, (sift_knn2 *)d_out,
                 ctx->knn_scratch);
+    HIP_TRY(hipGetLastError());
+    return SIFT_OK;
+}
+
+int sift_knn2_device_noalloc(sift_ctx *ctx, const void *d_q, int nq, const void *d_t, int nt, int train_index_base,
+                             void *d_out) {
+    if (!ctx || (nq > 0 && (!d_q || !d_out)) || (nt > 0 && !d_t)) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (nq < 0 || nt < 0) return fail(SIFT_ERR_INVALID, "negative count");
+    if (nq == 0) return SIFT_OK;
+    // two limits, both checked before anything is enqueued: the documented row limit, and the bytes this shape needs
+    const size_t need = knn_scratch_bytes(nq, nt);
+    if (nt > SIFT_KNN2_NOALLOC_MAX_TRAIN || need > KNN_STATIC_SCRATCH_BYTES)
+        return fail(SIFT_ERR_INVALID, "sift_knn2_device_noalloc: " + std::to_string(nq) + " queries x " + std::to_string(nt) +
+                                          " train rows need " + std::to_string(need) + " bytes of scratch, the static buffer holds " +
+                                          std::to_string(KNN_STATIC_SCRATCH_BYTES) + " (at most " +
+                                          std::to_string(SIFT_KNN2_NOALLOC_MAX_TRAIN) + " train rows per call)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // every word of the scratch a launch reads is written by that launch first (one bias per train row, one
+    // partial record per split and query), so nothing needs clearing between calls
+    launch_knn2(ctx->stream, (const uint8_t *)d_q, nq, (const uint8_t *)d_t, nt, train_index_base, (sift_knn2 *)d_out,
+                ctx->knn_static);
     HIP_TRY(hipGetLastError());
     return SIFT_OK;
 }
