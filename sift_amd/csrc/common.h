@@ -43,7 +43,8 @@ struct alignas(16) Grad {
 };
 
 // One frame batch's scale space.  gauss[o] is [frame][IMAGES][h][w] doubles,
-// dog[o] is [frame][NDOG][h][w]; rows are tightly packed (pitch = w).
+// rows tightly packed (pitch = w).  The difference-of-Gaussians level j is
+// gauss level j+1 minus gauss level j (sift.cpp:173), formed in registers by its readers.
 // grad[o] is [frame][SCALES][h][w] Grad: the gradient planes of Gaussian
 // levels 1..SCALES, the only levels orientation and descriptor windows sample
 // (null for octaves too small to hold a keypoint).
@@ -52,15 +53,11 @@ struct Pyramid {
     int w[MAX_OCTAVES];
     int h[MAX_OCTAVES];
     double *gauss[MAX_OCTAVES];
-    double *dog[MAX_OCTAVES];
     Grad *grad[MAX_OCTAVES];
 };
 
 __host__ __device__ inline size_t gauss_off(const Pyramid &p, int o, int frame, int lvl) {
     return ((size_t)frame * IMAGES + lvl) * (size_t)p.w[o] * p.h[o];
-}
-__host__ __device__ inline size_t dog_off(const Pyramid &p, int o, int frame, int lvl) {
-    return ((size_t)frame * NDOG + lvl) * (size_t)p.w[o] * p.h[o];
 }
 // layer = Gaussian level 1..SCALES
 __host__ __device__ inline size_t grad_off(const Pyramid &p, int o, int frame, int layer) {

@@ -10,15 +10,12 @@ int blur_radius_supported(int r);
 int pyramid_init_attributes();
 void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframes, const Pyramid &p, const Taps &taps,
                  int ntaps);
-void launch_blur_dog(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps);
+void launch_blur(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps);
 void launch_bgr_to_gray(hipStream_t st, const uint8_t *bgr, uint8_t *gray, size_t npix);
 
-// kernels_gradient.hip
-void launch_gradients(hipStream_t st, const Pyramid &p, int oct, int nframes);
-
 // kernels_extrema.hip
-void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
-                    FrameCounters *counters);
+void launch_extrema_gradients(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
+                              FrameCounters *counters);
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
                             DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
                             int32_t *n_localized);

@@ -1,5 +1,6 @@
-// Scale-space extrema: 3x3x3 scan with wave-ballot compaction, then per
-// candidate sub-pixel localisation and orientation assignment.
+// Scale-space extrema: 3x3x3 scan with wave-ballot compaction (fused with the
+// gradient planes the later stages sample), then per candidate sub-pixel
+// localisation and orientation assignment.
 //
 // Replaces scale_space_extrema_parallel::operator() and its helpers
 // (sift.cpp:227-448).  Floating-point operations are written in the order of a
@@ -8,8 +9,9 @@
 // orientation histogram is updated by lanes of a single wave only and the
 // partial histograms are combined in a fixed order, so it is reproducible run
 // to run.
-#include "common.h"
+#include "angle_table.h"
 #include "atan2_fast.h"
+#include "common.h"
 #include "kernels.h"
 
 namespace sa {
@@ -41,12 +43,56 @@ __device__ __forceinline__ double neighbour_lane(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// is_pixel_extremum (sift.cpp:264-281) for the three scanned layers.  A wave
-// owns 62 columns x 4 rows (its first and last lane only carry the halo
-// columns); a thread loads the six rows of its column in all five DoG levels
-// into registers, every load in flight together, and takes its left and right
-// neighbours from the adjacent lanes, so there is no LDS staging and no barrier.
-constexpr int EX_TW = 62, EX_TH = 16;
+__device__ const double kAtanKnots[33][2] = SA_ATAN_KNOTS;
+
+// Direction in degrees, (atan2(dy,dx)*180)/PI, as host libm would produce it.
+// The orientation histogram rounds direction*36/360 to the nearest bin, which
+// is discontinuous at the 36 boundaries (5 + 10 m degrees), and images with
+// exact diagonal symmetry put strong gradients within an ulp of them, where
+// the last bit of atan2 picks the bin.  Host libm's atan2 is correctly rounded
+// there; atan2_fast is good to an ulp.  So when the fast result lands within
+// 1e-9 bins of a boundary, the angle is recomputed as boundary +
+// atan(cross/dot) against a double-double table of the boundary directions,
+// which rounds correctly.  `knots` is the LDS copy of kAtanKnots.
+__device__ __forceinline__ double direction_degrees(double dy, double dx, const double (*knots)[2]) {
+    double a = atan2_fast(dy, dx, knots);
+    double orientation = div_pi(a * 180);
+    const double v = orientation * (BINS / 360.0);
+    const double fl = floor(v);
+    if (fabs(v - fl - 0.5) < 1e-9) {
+        const int m = (int)fl;
+        if (m >= -18 && m <= 17) {
+            const double *T = kBinBoundary[m + 18];
+            const double p1 = dy * T[2], e1 = fma(dy, T[2], -p1);  // dy*cos(b), exact as p1 + e1
+            const double p2 = dx * T[4], e2 = fma(dx, T[4], -p2);  // dx*sin(b)
+            // p1 and p2 agree to ~1e-10 here, so p1 - p2 is exact
+            const double cross = (p1 - p2) + ((e1 - e2) + (dy * T[3] - dx * T[5]));
+            const double dot = dx * T[2] + dy * T[4];
+            const double delta = cross / dot;  // |delta| < 1e-9: atan(delta) == delta to 1e-27
+            a = T[0] + (T[1] + delta);
+            orientation = div_pi(a * 180);
+        }
+    }
+    return orientation;
+}
+
+// One pass over the six Gaussian levels of an octave that produces both of their per-pixel consumers:
+//
+//  * the gradient planes of levels 1..3: per pixel the magnitude sqrt(dx^2 + dy^2) and the direction
+//    atan2(dy, dx) in degrees, with dx = L(y, x+1) - L(y, x-1), dy = L(y-1, x) - L(y+1, x), exactly the
+//    per-sample quantities of get_keypoint_orientations (sift.cpp:410-415) and of the descriptor loop
+//    (sift.cpp:507-510).  Orientation and descriptor windows of neighbouring keypoints overlap heavily, so
+//    evaluating the square root and the arctangent once per pixel instead of once per window sample removes
+//    most of the transcendental work of those stages; the values are the same;
+//  * is_pixel_extremum (sift.cpp:264-281) for the three scanned layers, on difference-of-Gaussians values
+//    formed in registers (level j+1 minus level j, sift.cpp:173).
+//
+// A wave owns 62 columns x 4 rows (its first and last lane only carry the halo columns); a thread loads the
+// six rows of its column in all six levels into registers, every load in flight together, and takes its left
+// and right neighbours from the adjacent lanes, so there is no LDS staging of pixels and no barrier after the
+// table copy.  Tiles cover the whole image (the gradient planes need every pixel); the extremum test is
+// confined to the BORDER-inset rectangle the reference scans (sift.cpp:188, :233).
+constexpr int EX_TW = 62, EX_TH = 16;  // 8 and 32 rows per workgroup (2 and 8 per thread) are slower: 15.1 and 17.9 ms against 14.9
 
 // max / min of finite doubles as the bare instruction.  fmax()/fmin() make the compiler quieten possible
 // signalling NaNs first (one extra v_max_f64 per operand that comes from memory or from a lane exchange),
@@ -62,28 +108,61 @@ __device__ __forceinline__ double min_finite(double a, double b) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
-                                                  FrameCounters *__restrict__ counters) {
+__global__ __launch_bounds__(256) void k_extrema_grad(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
+                                                       FrameCounters *__restrict__ counters) {
+    __shared__ double knots[33][2];
+    if (threadIdx.x < 66) (&knots[0][0])[threadIdx.x] = (&kAtanKnots[0][0])[threadIdx.x];
+    __syncthreads();
     const int w = p.w[oct], h = p.h[oct];
     const TileId tile = xcd_tile_id();
     const int f = tile.z;
     const size_t plane = (size_t)w * h;
-    const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
+    const double *G = p.gauss[oct] + (size_t)f * IMAGES * plane;
+    Grad *GR = p.grad[oct] + (size_t)f * SCALES * plane;
     const int lane = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // a wave is one row group
     constexpr int RY = EX_TH / 4;  // consecutive rows per thread
-    const int j = BORDER + tile.x * EX_TW + lane - 1;  // this lane's column
-    const int i0 = BORDER + tile.y * EX_TH + ty * RY;  // first tested row of this wave
-    if (i0 >= h - BORDER) return;
-    // Row and column indices are clamped into the image instead of branching: tested
-    // pixels lie BORDER pixels inside, so a clamped halo value is never compared.
-    const int gx = min(j, w - 1);
+    const int j = tile.x * EX_TW + lane - 1;  // this lane's column (-1 or w for a halo lane at the image edge)
+    const int i0 = tile.y * EX_TH + ty * RY;  // first row of this wave
+    if (i0 >= h) return;
+    // Row and column indices are clamped into the image instead of branching: a clamped value only ever
+    // stands in for a neighbour of a pixel on the image border, whose gradient is not evaluated and
+    // which lies outside the scanned rectangle.
+    const int gx = min(max(j, 0), w - 1);
+    double g[IMAGES][RY + 2];
+#pragma unroll
+    for (int lvl = 0; lvl < IMAGES; lvl++)
+#pragma unroll
+        for (int r = 0; r < RY + 2; r++)
+            g[lvl][r] = G[(size_t)lvl * plane + (size_t)min(max(i0 - 1 + r, 0), h - 1) * w + gx];
+    const bool own_column = lane >= 1 && lane <= EX_TW && j < w;
+
+    // ---- gradient planes of levels 1..SCALES
+#pragma unroll
+    for (int layer = 1; layer <= SCALES; layer++) {
+#pragma unroll
+        for (int q = 0; q < RY; q++) {
+            const int y = i0 + q;
+            const double l = neighbour_lane<true>(g[layer][q + 1]), r = neighbour_lane<false>(g[layer][q + 1]);
+            Grad gr = {0.0, 0.0};
+            // windows only sample 0 < x < w-1, 0 < y < h-1 (sift.cpp:407-409, :506)
+            if (j > 0 && j < w - 1 && y > 0 && y < h - 1) {
+                const double dx = r - l;
+                const double dy = g[layer][q] - g[layer][q + 2];
+                gr.mag = sqrt(dx * dx + dy * dy);
+                gr.ori = direction_degrees(dy, dx, knots);
+            }
+            if (own_column && y < h) GR[(size_t)(layer - 1) * plane + (size_t)y * w + j] = gr;
+        }
+    }
+
+    // ---- extrema of the difference-of-Gaussians levels: images[oct][lvl] = gauss[lvl + 1] - gauss[lvl] (sift.cpp:173)
     double v[NDOG][RY + 2];
 #pragma unroll
     for (int lvl = 0; lvl < NDOG; lvl++)
 #pragma unroll
-        for (int r = 0; r < RY + 2; r++) v[lvl][r] = D[(size_t)lvl * plane + (size_t)min(i0 - 1 + r, h - 1) * w + gx];
+        for (int r = 0; r < RY + 2; r++) v[lvl][r] = g[lvl + 1][r] - g[lvl][r];
     const double threshold = floor(0.5 * CONTRAST_THRESHOLD / SCALES * 255);  // sift.cpp:266
-    const bool column_tested = lane >= 1 && lane <= EX_TW && j < w - BORDER;
+    const bool column_tested = own_column && j >= BORDER && j < w - BORDER;
     // A positive centre must be >= its 26 neighbours, a negative one <= them
     // (sift.cpp:275-280), i.e. equal to the maximum (minimum) of the 3x3x3 block.
     // The block extremes are built separably: per level the 3-wide row
@@ -113,8 +192,8 @@ __global__ __launch_bounds__(256) void k_extrema(Pyramid p, int oct, Candidate *
                 const double c = v[img][q + 1];
                 const double hi = max_finite(max_finite(vmax[0][q], vmax[1][q]), vmax[2][q]);
                 const double lo = min_finite(min_finite(vmin[0][q], vmin[1][q]), vmin[2][q]);
-                const bool is_ext =
-                    column_tested && i < h - BORDER && fabs(c) > threshold && (c > 0 ? c >= hi : c <= lo);  // sift.cpp:268
+                const bool is_ext = column_tested && i >= BORDER && i < h - BORDER && fabs(c) > threshold &&
+                                    (c > 0 ? c >= hi : c <= lo);  // sift.cpp:268
                 const int slot = wave_append(is_ext, &counters[f].candidates);
                 if (slot >= 0) {
                     if (slot < cand_cap) {
@@ -212,7 +291,7 @@ __device__ __forceinline__ bool solve_normal3(const double H[3][3], const double
 __device__ int localize(const Pyramid &p, int f, int oct, int img, int i, int j, DevKeypoint &kpt) {
     const int w = p.w[oct], h = p.h[oct];
     const size_t plane = (size_t)w * h;
-    const double *D = p.dog[oct] + (size_t)f * NDOG * plane;
+    const double *G = p.gauss[oct] + (size_t)f * IMAGES * plane;
     double cube[3][3][3], grad[3], hess[3][3], res[3];
     int attempt;
     for (attempt = 0; attempt < 5; attempt++) {
@@ -223,7 +302,11 @@ __device__ int localize(const Pyramid &p, int f, int oct, int img, int i, int j,
             for (int a = 0; a < 3; a++)
 #pragma unroll
                 for (int b = 0; b < 3; b++)
-                    cube[k][a][b] = D[(size_t)(img - 1 + k) * plane + (size_t)(i - 1 + a) * w + (j - 1 + b)] * inv;
+                {
+                    // DoG level img-1+k = Gaussian level img+k minus Gaussian level img-1+k (sift.cpp:173)
+                    const size_t at = (size_t)(img - 1 + k) * plane + (size_t)(i - 1 + a) * w + (j - 1 + b);
+                    cube[k][a][b] = (G[at + plane] - G[at]) * inv;
+                }
         grad[0] = 0.5 * (cube[1][1][2] - cube[1][1][0]);
         grad[1] = 0.5 * (cube[1][2][1] - cube[1][0][1]);
         grad[2] = 0.5 * (cube[2][1][1] - cube[0][1][1]);
@@ -444,12 +527,13 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
 
 }  // namespace
 
-void launch_extrema(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
-                    FrameCounters *counters) {
+void launch_extrema_gradients(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
+                              FrameCounters *counters) {
     const int w = p.w[oct], h = p.h[oct];
-    if (w <= 2 * BORDER || h <= 2 * BORDER) return;  // empty scan range (sift.cpp:188, :233)
-    dim3 grid((w - 2 * BORDER + EX_TW - 1) / EX_TW, (h - 2 * BORDER + EX_TH - 1) / EX_TH, nframes);
-    hipLaunchKernelGGL(k_extrema, grid, dim3(256), 0, st, p, oct, cand, cand_cap, counters);
+    // empty scan range (sift.cpp:188, :233): no keypoint can come from this octave, so nothing samples its gradients
+    if (w <= 2 * BORDER || h <= 2 * BORDER || !p.grad[oct]) return;
+    dim3 grid((w + EX_TW - 1) / EX_TW, (h + EX_TH - 1) / EX_TH, nframes);
+    hipLaunchKernelGGL(k_extrema_grad, grid, dim3(256), 0, st, p, oct, cand, cand_cap, counters);
 }
 
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,

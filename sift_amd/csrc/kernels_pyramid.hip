@@ -1,22 +1,22 @@
-// Gaussian scale-space pyramid with fused difference-of-Gaussians.
+// Gaussian scale-space pyramid.
 //
-// Replaces gen_gaussian_images (sift.cpp:132-156), gen_dog_images
-// (sift.cpp:161-177) and the base-image part of the constructor
-// (sift.cpp:40-42).  Every blur is one launch that reads its input level once
-// and writes the blurred level, the DoG level (blurred minus input,
-// sift.cpp:173) and, for level 3, the nearest-neighbour half-size base of the
-// next octave (sift.cpp:152-153) in the same pass.
+// Replaces gen_gaussian_images (sift.cpp:132-156) and the base-image part of
+// the constructor (sift.cpp:40-42).  Every blur is one launch that reads its
+// input level once and writes the blurred level and, for level 3, the
+// nearest-neighbour half-size base of the next octave (sift.cpp:152-153) in
+// the same pass.  The difference-of-Gaussians images of gen_dog_images
+// (sift.cpp:161-177) are never stored: their only readers, the extrema scan
+// and the localisation, subtract two Gaussian levels in registers, which is
+// the same IEEE operation on the same operands.
 //
 // Marching structure: a workgroup owns a strip of 128 (or 64) columns and walks
 // down it 16 (or 32) rows at a time.  Each step stages the new input rows (plus
-// the horizontal halo) in one of two LDS buffers, row-filters them into a ring
+// the horizontal halo) in an LDS buffer, row-filters them into a ring
 // of row-filtered rows (also LDS) and then column-filters the output rows whose
 // 2R+1 supports are now complete.  Every input row is read from HBM and
-// row-filtered once per strip (no vertical halo recompute); the un-filtered
-// centre values the DoG needs come from the two staging buffers, not from a
-// second global read; the next step's input is prefetched into registers while
-// the current step computes; every thread has exactly one row item and one
-// column item per step.  Rows above/below the image are the reflected rows
+// row-filtered once per strip (no vertical halo recompute); the next step's
+// input is prefetched into registers while the current step computes; every
+// thread has exactly one row item and one column item per step.  Rows above/below the image are the reflected rows
 // (BORDER_REFLECT_101), re-filtered.
 //
 // Arithmetic order is fixed (and contraction is off for this file) so that
@@ -32,7 +32,8 @@ namespace {
 
 // Strip geometry.  Filters up to 21 taps use 128-column strips walked 16 rows at a time
 // (1 KB contiguous per row: fewer, longer bursts and half the column halo); the 27-tap filter
-// would then need 83 KB of LDS and fit one workgroup per CU, so it keeps 64 columns x 32 rows.
+// is bound by its arithmetic and takes the same time either way (3.70 ms per 64 1080p frames with
+// 128 x 16 and with 64 x 32); it keeps 64 columns x 32 rows, the smaller LDS footprint.
 
 // Threads per workgroup: 256 (8 consecutive outputs per thread in either pass) for the short
 // filters, 512 (4 outputs per thread, half the registers, twice the waves per SIMD) for the
@@ -49,7 +50,7 @@ struct MarchGeom {
     static constexpr int RING = MCH + 2 * R;
     static constexpr int PR = TW + 1;      // odd pitch: lane<->row writes are conflict-free
     static constexpr int NLOAD = (MCH * COLS + NTHREADS - 1) / NTHREADS;
-    static constexpr size_t LDS_BYTES = (2 * (size_t)MCH * PIN + (size_t)RING * PR) * sizeof(double);
+    static constexpr size_t LDS_BYTES = ((size_t)MCH * PIN + (size_t)RING * PR) * sizeof(double);
 };
 
 // Source of the blur levels: the previous Gaussian level.
@@ -111,15 +112,14 @@ struct UpsampleSource {
     }
 };
 
-// grid: (strips, vertical segments, frames).  `dog` and `nxt` may be null.
+// grid: (strips, vertical segments, frames).  `nxt` may be null.
 template <int R, class Source>
-__device__ __forceinline__ void march(const Source source, double *__restrict__ out, double *__restrict__ dog,
+__device__ __forceinline__ void march(const Source source, double *__restrict__ out,
                                       double *__restrict__ nxt, int w, int h, int nw, int nh, int strip_h,
                                       const Taps &taps, double *smem, const TileId tile) {
     using G = MarchGeom<R>;
     constexpr int NTHREADS = G::NTHREADS, CX = G::CX, CY = G::CY, TW = G::TW, MCH = G::MCH;
-    static_assert(R < MCH, "the centre rows of one step lie in the last two staging buffers");
-    double *ring = smem + 2 * MCH * G::PIN;
+    double *ring = smem + MCH * G::PIN;
     const int tid = threadIdx.x;
     const int tx0 = tile.x * TW;
     const int ys = tile.y * strip_h;
@@ -193,7 +193,9 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
 
     fetch(0);
     for (int s = 0; s < nsteps; s++) {
-        double *s_in = smem + (s & 1) * (MCH * G::PIN);
+        // One staging tile is enough: every wave has finished the row pass of the previous step (it lies before
+        // that step's second barrier) when the first wave gets here.
+        double *s_in = smem;
         stage(s, s_in);
         __syncthreads();  // staging tile complete; previous step's column pass is done with the ring
         if (s + 1 < nsteps) fetch(s + 1);
@@ -220,16 +222,6 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
         // row group: its ring slots, centre rows and output rows are scalars.
         const int x = tid & (TW - 1), cy = __builtin_amdgcn_readfirstlane(tid / TW);
         const int rel0 = MCH * s + cy * CY - R;  // strip-relative index of the first output row
-        // Un-filtered centres of this thread's output rows: strip-relative row rel was staged in
-        // step rel / MCH, i.e. in this step's buffer or in the other one.  They are read BEFORE the
-        // barrier: after it, a wave that is done with its column pass starts the next step and
-        // overwrites the other buffer.
-        double centre[CY];
-#pragma unroll
-        for (int m = 0; m < CY; m++) {
-            const int rel = rel0 + m;
-            centre[m] = (dog && rel >= 0) ? smem[((rel / MCH) & 1) * (MCH * G::PIN) + (rel % MCH) * G::PIN + x + R] : 0.0;
-        }
         __syncthreads();
         {
             const int y0 = ys - R + rel0;  // image row of the first output row
@@ -258,7 +250,6 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                         const size_t orow = (size_t)y * w;
                         const unsigned xoff = (unsigned)gx * 8u;  // byte offset inside the row
                         *reinterpret_cast<double *>(reinterpret_cast<char *>(out + orow) + xoff) = acc[m];
-                        if (dog) *reinterpret_cast<double *>(reinterpret_cast<char *>(dog + orow) + xoff) = acc[m] - centre[m];
                         if (nxt && !(y & 1) && (y >> 1) < nh) {
                             const int hx = gx >> 1;
                             if (!(gx & 1) && hx < nw)
@@ -274,16 +265,15 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
 // One blur level of one octave for every frame of the batch.
 template <int R>
 __global__ __launch_bounds__(MarchGeom<R>::NTHREADS) void k_blur_march(const double *__restrict__ in, double *__restrict__ out,
-                                                          double *__restrict__ dog, double *__restrict__ next, int w,
-                                                          int h, int nw, int nh, size_t in_frame_stride,
-                                                          size_t dog_frame_stride, size_t next_frame_stride,
+                                                          double *__restrict__ next, int w, int h, int nw, int nh,
+                                                          size_t in_frame_stride, size_t next_frame_stride,
                                                           int strip_h, Taps taps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const TileId tile = xcd_tile_id();
     const size_t f = tile.z;
     const LevelSource source{in + f * in_frame_stride, w};
-    march<R>(source, out + f * in_frame_stride, dog + f * dog_frame_stride,
-             next ? next + f * next_frame_stride : nullptr, w, h, nw, nh, strip_h, taps, smem, tile);
+    march<R>(source, out + f * in_frame_stride, next ? next + f * next_frame_stride : nullptr, w, h, nw, nh, strip_h, taps,
+             smem, tile);
 }
 
 // gray u8 -> double -> 2x bilinear upsample -> base blur (sift.cpp:30, :40-42).
@@ -295,7 +285,7 @@ __global__ __launch_bounds__(MarchGeom<R>::NTHREADS) void k_base_march(const uin
     const TileId tile = xcd_tile_id();
     const size_t f = tile.z;
     const UpsampleSource source{frames + f * (size_t)W * H, W, H};
-    march<R>(source, out + f * out_frame_stride, nullptr, nullptr, 2 * W, 2 * H, 0, 0, strip_h, taps, smem, tile);
+    march<R>(source, out + f * out_frame_stride, nullptr, 2 * W, 2 * H, 0, 0, strip_h, taps, smem, tile);
 }
 
 // strips cut vertically so that the launch has >= ~2048 workgroups
@@ -319,7 +309,6 @@ void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nfram
     const size_t plane = (size_t)w * h;
     const double *in = p.gauss[oct] + (size_t)(lvl - 1) * plane;
     double *out = p.gauss[oct] + (size_t)lvl * plane;
-    double *dog = p.dog[oct] + (size_t)(lvl - 1) * plane;
     double *next = nullptr;
     int nw = 0, nh = 0;
     size_t next_stride = 0;
@@ -332,8 +321,8 @@ void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nfram
     dim3 grid;
     int strip_h;
     strip_grid<R>(w, h, nframes, grid, strip_h);
-    hipLaunchKernelGGL(k_blur_march<R>, grid, dim3(MarchGeom<R>::NTHREADS), MarchGeom<R>::LDS_BYTES, st, in, out, dog, next, w, h,
-                       nw, nh, (size_t)IMAGES * plane, (size_t)NDOG * plane, next_stride, strip_h, taps);
+    hipLaunchKernelGGL(k_blur_march<R>, grid, dim3(MarchGeom<R>::NTHREADS), MarchGeom<R>::LDS_BYTES, st, in, out, next, w, h, nw, nh,
+                       (size_t)IMAGES * plane, next_stride, strip_h, taps);
 }
 
 // cvtColor(BGR2GRAY) on 8-bit data (sift.cpp:29): OpenCV 4.x integer formula
@@ -389,7 +378,7 @@ void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframe
                        (size_t)IMAGES * w * h, strip_h, taps);
 }
 
-void launch_blur_dog(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps) {
+void launch_blur(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps) {
     switch (ntaps / 2) {
         case 5: launch_blur_r<5>(st, p, oct, lvl, nframes, taps); break;
         case 6: launch_blur_r<6>(st, p, oct, lvl, nframes, taps); break;

@@ -242,7 +242,6 @@ int sift_batch_destroy(sift_batch *b) {
     hipStreamSynchronize(b->ctx->stream);
     for (int o = 0; o < MAX_OCTAVES; o++) {
         if (b->pyr.gauss[o]) hipFree(b->pyr.gauss[o]);
-        if (b->pyr.dog[o]) hipFree(b->pyr.dog[o]);
         if (b->pyr.grad[o]) hipFree(b->pyr.grad[o]);
     }
     hipFree(b->d_frames);
@@ -316,8 +315,6 @@ int sift_batch_create(sift_ctx *ctx, int w, int h, int max_frames, int max_keypo
         const size_t plane = (size_t)ow * oh * sizeof(double);
         if ((e = hipMalloc((void **)&b->pyr.gauss[o], plane * IMAGES * max_frames)) != hipSuccess)
             return cleanup(e, "hipMalloc(gauss)");
-        if ((e = hipMalloc((void **)&b->pyr.dog[o], plane * NDOG * max_frames)) != hipSuccess)
-            return cleanup(e, "hipMalloc(dog)");
         // gradient planes only where the scan range is non-empty (sift.cpp:188, :233)
         if (ow > 2 * BORDER && oh > 2 * BORDER &&
             (e = hipMalloc((void **)&b->pyr.grad[o], (size_t)ow * oh * sizeof(Grad) * SCALES * max_frames)) != hipSuccess)
@@ -438,12 +435,11 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
         hipStream_t aux = ctx->aux;
         launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps);
         for (int o = 0; o < b->pyr.octaves; o++) {
-            for (int lvl = 1; lvl <= IMAGES - 3; lvl++) launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
+            for (int lvl = 1; lvl <= IMAGES - 3; lvl++) launch_blur(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
             HIP_TRY(hipEventRecord(ctx->oct_ready[o], st));
             HIP_TRY(hipStreamWaitEvent(aux, ctx->oct_ready[o], 0));
-            for (int lvl = IMAGES - 2; lvl < IMAGES; lvl++) launch_blur_dog(aux, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
-            if (b->pyr.grad[o]) launch_gradients(aux, b->pyr, o, n);
-            launch_extrema(aux, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters);
+            for (int lvl = IMAGES - 2; lvl < IMAGES; lvl++) launch_blur(aux, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
+            launch_extrema_gradients(aux, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters);
         }
         HIP_TRY(hipEventRecord(ctx->aux_done, aux));
         HIP_TRY(hipStreamWaitEvent(st, ctx->aux_done, 0));
@@ -451,11 +447,10 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
         TIMED(SIFT_STAGE_BASE, launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
         for (int o = 0; o < b->pyr.octaves; o++)
             for (int lvl = 1; lvl < IMAGES; lvl++)
-                TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur_dog(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
+                TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
         for (int o = 0; o < b->pyr.octaves; o++)
-            if (b->pyr.grad[o]) TIMED(SIFT_STAGE_GRADIENT, launch_gradients(st, b->pyr, o, n));
-        for (int o = 0; o < b->pyr.octaves; o++)
-            TIMED(SIFT_STAGE_EXTREMA, launch_extrema(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
+            if (b->pyr.grad[o])
+                TIMED(SIFT_STAGE_EXTREMA, launch_extrema_gradients(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
     }
     TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_sorted, b->d_oriented,
                                                       b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames));
@@ -567,14 +562,21 @@ int sift_batch_get_level(sift_batch *b, int frame, int oct, int lvl, int kind, d
         return fail(SIFT_ERR_INVALID, "level out of range");
     HIP_TRY(hipSetDevice(b->ctx->device));
     const size_t plane = (size_t)b->pyr.w[oct] * b->pyr.h[oct];
-    const double *src = kind == SIFT_LEVEL_GAUSS ? b->pyr.gauss[oct] + gauss_off(b->pyr, oct, frame, lvl)
-                                                 : b->pyr.dog[oct] + dog_off(b->pyr, oct, frame, lvl);
+    // images[oct][lvl] = gauss_images[oct][lvl + 1] - gauss_images[oct][lvl] (sift.cpp:173) is not kept on the device:
+    // both Gaussian levels come down and are subtracted here, the same IEEE operation the kernels perform
+    const int ncopy = kind == SIFT_LEVEL_DOG ? 2 : 1;
+    const double *src = b->pyr.gauss[oct] + gauss_off(b->pyr, oct, frame, lvl);  // levels are adjacent planes
     void *stage = nullptr;
-    int rc = stage_in(b->ctx, plane * sizeof(double), &stage);
+    int rc = stage_in(b->ctx, ncopy * plane * sizeof(double), &stage);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(stage, src, plane * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(stage, src, ncopy * plane * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-    std::memcpy(out, stage, plane * sizeof(double));
+    const double *lo = static_cast<const double *>(stage), *hi = lo + plane;
+    if (kind == SIFT_LEVEL_DOG) {
+        for (size_t i = 0; i < plane; i++) out[i] = hi[i] - lo[i];
+    } else {
+        std::memcpy(out, stage, plane * sizeof(double));
+    }
     return SIFT_OK;
 }
 
