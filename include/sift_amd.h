@@ -69,8 +69,8 @@ int sift_ctx_destroy(sift_ctx *ctx);
 /* The HIP stream (hipStream_t) every call of this context enqueues on. */
 int sift_ctx_stream(sift_ctx *ctx, void **stream);
 int sift_ctx_synchronize(sift_ctx *ctx);
-/* Initial capacity (candidates and keypoints per frame) of the workspace behind sift_extract_*; 0 restores
- * the default, max(8192, pixels/16).  The reference's vectors (sift.hpp:93-94) grow without bound: when a frame
+/* Initial capacity (candidates and keypoints per frame) of the workspaces behind sift_extract_* and
+ * sift_extract_batch_u8; 0 restores the default, max(8192, pixels/16).  The reference's vectors (sift.hpp:93-94) grow without bound: when a frame
  * exceeds the capacity, sift_extract_* runs it again in a larger workspace, so this is a memory knob only. */
 int sift_ctx_set_single_image_capacity(sift_ctx *ctx, int max_keypoints);
 
@@ -125,6 +125,12 @@ int sift_batch_download(sift_batch *b, int frame, int capacity, sift_keypoint *k
 /* Device pointers of a frame's final keypoints (32-byte records whose first 28
  * bytes are a sift_keypoint) and 128-byte descriptors, valid until the next run. */
 int sift_batch_result_device_ptrs(sift_batch *b, int frame, void **keypoints, void **desc_u8);
+
+/* Measurement aid: the work the descriptor stage (sift.cpp:464-584) did for the keypoints of the last completed run,
+ * counted by a pass over the same window samples: work[2*f] = samples that contribute to frame f's descriptors
+ * (inside the rotated 4x4 window, non-zero gradient), work[2*f+1] = histogram updates they make (two orientation bins
+ * for each of up to four cells).  Synchronous. */
+int sift_batch_descriptor_work(sift_batch *b, int n_frames, int64_t *work);
 
 /* Parity/debug accessors (host copies of intermediate images and lists). */
 #define SIFT_LEVEL_GAUSS 0 /* gauss_images[oct][lvl], lvl 0..5 (sift.hpp:115) */
@@ -200,6 +206,47 @@ int sift_knn2_merge_device(sift_ctx *ctx, const void *d_parts, int nparts, int n
  * a query is good when sqrtf(d1) < 3*min_dist.  Host only.  Returns the number
  * of good matches through *n_good and their query indices in good_idx. */
 int sift_match_min_dist_filter(const sift_knn2 *knn, int nq, int32_t *good_idx, int32_t *n_good);
+
+/* ---- all GPUs of a node from one process ---------------------------------------- */
+/* The reference is one C++ program (main.cpp:22-152); a group lets such a program spread the two stages that shard
+ * over several GPUs without leaving the process: frames are independent (contiguous blocks of frames per GPU, no
+ * collective), and the matcher's train set is cut into contiguous shards whose per-GPU top-2 results are exchanged
+ * with RCCL and merged.  A group borrows its contexts (one per GPU, all distinct GPUs); they must outlive it.
+ * Calls on a group must not overlap with other calls on its contexts. */
+typedef struct sift_group sift_group;
+int sift_group_create(sift_ctx *const *ctxs, int ngpu, sift_group **out);
+int sift_group_destroy(sift_group *g);
+int sift_group_size(const sift_group *g);
+
+/* Host only: the contiguous near-equal split used for frames and train rows, part r = [bounds[r], bounds[r+1]),
+ * bounds[r] = n*r/parts; bounds holds parts+1 entries. */
+int sift_shard_bounds(int64_t n, int parts, int64_t *bounds);
+/* Host only: the query slices of the sharded matcher's exchange.  Every part sends `slice_len` records (the last
+ * slice is padded) of its partial results to each peer; part `rank` merges and owns queries [own_lo, own_hi). */
+int sift_knn2_exchange_plan(int nq, int parts, int rank, int32_t *slice_len, int32_t *own_lo, int32_t *own_hi);
+
+/* exec() (sift.hpp:25) over n same-sized 8-bit gray frames held in host memory, frame i at
+ * frames + i*frame_stride with row_stride bytes per row: frames are dealt to the GPUs of the group in contiguous
+ * blocks, and every GPU runs its block frames_per_launch (<= 0: 16) frames at a time through two workspaces, so that
+ * the upload of the next chunk and the download of the previous one overlap the kernels.  results[i] receives
+ * frame i's keypoints (clean_keypoints order) and 128-byte descriptors in library-owned buffers released by
+ * sift_frame_results_free.  A frame that exceeds the workspace's list capacity is run again on its own in a larger
+ * one, as sift_extract_gray8 does. */
+typedef struct sift_frame_result {
+    int32_t n;
+    sift_keypoint *keypoints;
+    uint8_t *descriptors; /* n x 128, values 0..255 (at most 102 in practice, sift.cpp:566-573) */
+    sift_frame_counts counts;
+} sift_frame_result;
+int sift_extract_batch_u8(sift_group *g, const uint8_t *frames, int n, int w, int h, size_t row_stride, size_t frame_stride,
+                          int frames_per_launch, sift_frame_result *results);
+int sift_frame_results_free(sift_frame_result *results, int n);
+
+/* sift_knn2_u8 with the train set sharded over the GPUs of the group (main.cpp:75 at a size one GPU should not
+ * hold): GPU r searches train rows [bounds[r], bounds[r+1]) for all queries, the partial top-2 records (16 bytes per
+ * query) of query slice s travel to GPU s (grouped ncclSend/ncclRecv), which merges them under (distance, index)
+ * order and applies the ratio test.  Results are identical to sift_knn2_u8 whatever the number of GPUs. */
+int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t, int nt, sift_knn2 *out, uint8_t *accept);
 
 /* ---- homography from matches ------------------------------------------------ */
 /* Replaces cv::findHomography(obj, scene, RANSAC, 3, mask) at main.cpp:105 (OpenCV

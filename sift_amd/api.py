@@ -38,10 +38,12 @@ EXPORTED_SYMBOLS = (
     "sift_result_free", "sift_result_get_f32", "sift_batch_create", "sift_batch_destroy",
     "sift_batch_frames_device_ptr", "sift_batch_set_external_frames", "sift_batch_upload_gray8", "sift_batch_upload_bgr8", "sift_batch_run",
     "sift_batch_counts", "sift_batch_download", "sift_batch_result_device_ptrs", "sift_batch_get_level",
-    "sift_batch_get_candidates", "sift_batch_get_oriented", "sift_batch_run_profiled", "sift_knn2_u8",
+    "sift_batch_get_candidates", "sift_batch_get_oriented", "sift_batch_run_profiled", "sift_batch_descriptor_work", "sift_knn2_u8",
     "sift_knn2_f32", "sift_knn2_device", "sift_knn2_device_noalloc", "sift_knn2_merge_device", "sift_match_min_dist_filter",
     "sift_find_homography", "sift_warp_perspective_bgr8", "sift_stitch_pair_bgr8",
     "sift_synth_dead_leaves", "sift_synth_descriptors", "sift_synth_queries",
+    "sift_group_create", "sift_group_destroy", "sift_group_size", "sift_shard_bounds", "sift_knn2_exchange_plan",
+    "sift_extract_batch_u8", "sift_frame_results_free", "sift_knn2_sharded",
 )
 
 
@@ -64,6 +66,10 @@ class _Result(C.Structure):
 class _HomographyInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("found", "iterations", "best_iteration", "inliers", "lm_iterations", "hypotheses_scored")]
+
+
+class _FrameResult(C.Structure):
+    _fields_ = [("n", C.c_int32), ("keypoints", C.c_void_p), ("descriptors", C.c_void_p), ("counts", _FrameCounts)]
 
 
 class _StageTimes(C.Structure):
@@ -131,6 +137,7 @@ def lib():
     L.sift_batch_get_candidates.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_int32)]
     L.sift_batch_get_oriented.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_int32)]
     L.sift_batch_run_profiled.argtypes = [vp, ci, C.POINTER(_StageTimes)]
+    L.sift_batch_descriptor_work.argtypes = [vp, ci, vp]
     L.sift_knn2_u8.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     L.sift_knn2_f32.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     L.sift_knn2_device.argtypes = [vp, vp, ci, vp, ci, ci, vp]
@@ -140,6 +147,14 @@ def lib():
     L.sift_warp_perspective_bgr8.argtypes = [vp, vp, ci, ci, sz, vp, ci, ci, vp]
     L.sift_stitch_pair_bgr8.argtypes = [vp, vp, ci, ci, sz, vp, ci, ci, sz, vp, vp, C.POINTER(ci)]
     L.sift_find_homography.argtypes = [vp, vp, vp, ci, C.c_double, ci, C.c_double, vp, vp, C.POINTER(_HomographyInfo)]
+    L.sift_group_create.argtypes = [pvp, ci, pvp]
+    L.sift_group_destroy.argtypes = [vp]
+    L.sift_group_size.argtypes = [vp]
+    L.sift_shard_bounds.argtypes = [i64, ci, vp]
+    L.sift_knn2_exchange_plan.argtypes = [ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.sift_extract_batch_u8.argtypes = [vp, vp, ci, ci, ci, sz, sz, ci, C.POINTER(_FrameResult)]
+    L.sift_frame_results_free.argtypes = [C.POINTER(_FrameResult), ci]
+    L.sift_knn2_sharded.argtypes = [vp, vp, ci, vp, ci, vp, vp]
     L.sift_synth_dead_leaves.argtypes = [u64, u64, ci, ci, vp]
     L.sift_synth_descriptors.argtypes = [u64, i64, vp]
     L.sift_synth_queries.argtypes = [u64, vp, i64, i64, vp]
@@ -181,6 +196,20 @@ def synth_queries(seed, train, nq):
     out = np.empty((nq, 128), np.uint8)
     _check(lib().sift_synth_queries(seed, train.ctypes.data, train.shape[0], nq, out.ctypes.data))
     return out
+
+
+def shard_bounds(n, parts):
+    """Contiguous near-equal split of range(n): part r = [b[r], b[r+1])."""
+    out = np.zeros(parts + 1, np.int64)
+    _check(lib().sift_shard_bounds(n, parts, out.ctypes.data))
+    return out.tolist()
+
+
+def knn2_exchange_plan(nq, parts, rank):
+    """(slice_len, own_lo, own_hi) of the sharded matcher's query slices."""
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib().sift_knn2_exchange_plan(nq, parts, rank, C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def min_dist_filter(knn):
@@ -317,6 +346,68 @@ class Context:
         _check(lib().sift_knn2_merge_device(self._h, d_parts, nparts, nq, d_out, d_accept))
 
 
+class Group:
+    """Several GPUs of a node driven from this process: frame-sharded extraction and the train-sharded matcher."""
+
+    def __init__(self, contexts):
+        self.contexts = list(contexts)
+        arr = (C.c_void_p * len(self.contexts))(*[c._h for c in self.contexts])
+        self._h = C.c_void_p()
+        _check(lib().sift_group_create(arr, len(self.contexts), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().sift_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extract_batch(self, frames, frames_per_launch=0):
+        """frames: [n, h, w] uint8 host array.  Returns a list of (keypoints, descriptors uint8 [k, 128], counts)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        res = (_FrameResult * n)()
+        _check(lib().sift_extract_batch_u8(self._h, frames.ctypes.data, n, w, h, frames.strides[1], frames.strides[0],
+                                           frames_per_launch, res))
+        try:
+            out = []
+            for r in res:
+                kps = np.zeros(r.n, KEYPOINT_DTYPE)
+                desc = np.zeros((r.n, 128), np.uint8)
+                if r.n:
+                    C.memmove(kps.ctypes.data, r.keypoints, r.n * KEYPOINT_DTYPE.itemsize)
+                    C.memmove(desc.ctypes.data, r.descriptors, r.n * 128)
+                out.append((kps, desc, {"candidates": r.counts.candidates, "oriented": r.counts.oriented,
+                                        "keypoints": r.counts.keypoints}))
+        finally:
+            lib().sift_frame_results_free(res, n)
+        return out
+
+    def extract_batch_raw(self, frames, frames_per_launch=0):
+        """Same call without the conversion to numpy: returns (total keypoints, free()) for throughput timing."""
+        n, h, w = frames.shape
+        res = (_FrameResult * n)()
+        _check(lib().sift_extract_batch_u8(self._h, frames.ctypes.data, n, w, h, frames.strides[1], frames.strides[0],
+                                           frames_per_launch, res))
+        total = sum(r.n for r in res)
+        lib().sift_frame_results_free(res, n)
+        return total
+
+    def knn2(self, q, t):
+        """Exact top-2 + ratio test, train set sharded over the group's GPUs.  q, t: Nx128 uint8 (values <= 127)."""
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        out = np.zeros(q.shape[0], KNN2_DTYPE)
+        acc = np.zeros(q.shape[0], np.uint8)
+        _check(lib().sift_knn2_sharded(self._h, q.ctypes.data, q.shape[0], t.ctypes.data, t.shape[0], out.ctypes.data,
+                                       acc.ctypes.data))
+        return out, acc
+
+
 class Batch:
     """Pyramid workspace for up to max_frames same-sized frames resident in HBM."""
 
@@ -364,6 +455,12 @@ class Batch:
         t = _StageTimes()
         _check(lib().sift_batch_run_profiled(self._h, n_frames, C.byref(t)))
         return {STAGE_NAMES[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(STAGE_NAMES))}
+
+    def descriptor_work(self, n_frames):
+        """Per frame (contributing window samples, histogram updates) of the descriptor stage of the last run."""
+        out = np.zeros((n_frames, 2), np.int64)
+        _check(lib().sift_batch_descriptor_work(self._h, n_frames, out.ctypes.data))
+        return out
 
     def counts(self, n_frames):
         out = np.zeros(n_frames, COUNTS_DTYPE)

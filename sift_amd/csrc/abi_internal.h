@@ -1,0 +1,79 @@
+// Internals shared by the translation units that implement the C ABI (contexts, batches, error reporting).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace sa {
+
+// Records `msg` as the calling thread's last error and returns `code`.
+int fail(int code, const std::string &msg);
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return sa::fail(SIFT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+// Grow-only device buffer: frees and reallocates when `want` exceeds `*have`.
+int ensure_bytes(void **buf, size_t *have, size_t want);
+
+}  // namespace sa
+
+struct sift_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void *knn_scratch = nullptr;
+    size_t knn_scratch_bytes = 0;
+    void *knn_static = nullptr;  // this device's copy of the matcher's file-scope scratch array (sift_knn2_device_noalloc)
+    void *knn_io = nullptr;  // device staging of the host-buffer matcher calls
+    size_t knn_io_bytes = 0;
+    void *h_work = nullptr;  // device workspace of sift_find_homography
+    size_t h_work_bytes = 0;
+    void *st_work = nullptr;  // device workspace of the composition calls
+    size_t st_work_bytes = 0;
+    hipStream_t aux = nullptr;              // second stream of the small-workload schedule (run_pipeline)
+    hipEvent_t oct_ready[sa::MAX_OCTAVES] = {};  // level 3 of octave o is complete
+    hipEvent_t aux_done = nullptr;
+    void *pinned = nullptr;  // page-locked host staging of the single-image calls and of result downloads
+    size_t pinned_bytes = 0;
+    sift_batch *cached = nullptr;  // workspace of the single-image calls
+    int single_cap = 0;            // its initial per-frame list capacity (0: the batch default)
+};
+
+struct sift_batch {
+    sift_ctx *ctx = nullptr;
+    int w = 0, h = 0, max_frames = 0;
+    sa::Pyramid pyr{};
+    uint8_t *d_frames = nullptr;
+    const uint8_t *d_ext_frames = nullptr;  // caller-owned frames, if set
+    uint8_t *d_bgr = nullptr;  // one frame of BGR staging, allocated on first use
+    sa::Candidate *d_cand = nullptr;
+    int cand_cap = 0;
+    sa::DevKeypoint *d_oriented = nullptr, *d_sorted = nullptr, *d_final = nullptr;
+    uint8_t *d_flags = nullptr;
+    int kp_cap = 0;
+    uint8_t *d_desc = nullptr;
+    sa::FrameCounters *d_counters = nullptr;
+    unsigned long long *d_work = nullptr;  // [max_frames][2], sift_batch_descriptor_work only
+    int32_t *d_cursors = nullptr;  // [3][max_frames]: (unused), descriptor cursor, localised count
+    sa::Taps base_taps{};
+    int base_ntaps = 0;
+    sa::Taps lvl_taps[sa::IMAGES]{};
+    int lvl_ntaps[sa::IMAGES]{};
+    std::vector<hipEvent_t> events;
+};
+
+namespace sa {
+
+// exec() (sift.cpp:67-98) for frames [0, n) of a batch as a sequence of launches on the context stream;
+// `times` (may be null) receives per-stage device times and serialises the run.
+int run_pipeline(sift_batch *b, int n, sift_stage_times *times);
+
+}  // namespace sa

@@ -28,6 +28,11 @@ void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevK
 void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
                         const FrameCounters *counters, int32_t *cursors, uint8_t *desc);
 
+// Per frame {contributing samples, LDS atomics} of the descriptor stage for the keypoints of the last run (`cursors` and
+// `work` must be zero on entry).
+void launch_descriptor_work(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
+                            const FrameCounters *counters, int32_t *cursors, unsigned long long *work);
+
 // kernels_knn.hip
 size_t knn_scratch_bytes(int nq, int nt);
 // Size of the file-scope device array behind sift_knn2_device_noalloc.  Partial results need at most

@@ -66,15 +66,22 @@ struct DescShared {
     int idx;
 };
 
+// COUNT = false is the descriptor kernel.  COUNT = true walks the same samples with the same tests but, instead of
+// scattering them, counts them: per frame the samples that contribute (non-zero gradient inside the rotated window)
+// and the LDS double atomics they would issue (two per cell corner that lies inside the 4x4 grid), into
+// work[frame][0..1].  It exists so that the kernel's throughput can be stated in the unit that bounds it.
+template <bool COUNT>
 __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
                                                       const FrameCounters *__restrict__ counters,
-                                                      int32_t *__restrict__ cursors, uint8_t *__restrict__ desc) {
+                                                      int32_t *__restrict__ cursors, uint8_t *__restrict__ desc,
+                                                      unsigned long long *__restrict__ work) {
     __shared__ DescShared sm;
     const int f = blockIdx.y;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int n = counters[f].keypoints;
     if (n > kp_cap) n = kp_cap;
+    unsigned n_samples = 0, n_atomics = 0;  // COUNT only; per lane, per keypoint (a window holds < 2^17 samples)
     // Keypoints are pulled from a per-frame cursor: window areas differ by a factor of 25 between keypoints, and a
     // fixed round-robin deal of keypoints to workgroups measured 4 % slower than the cursor's dynamic balance.
     for (;;) {
@@ -212,6 +219,11 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                         const bool r1 = (unsigned)(row_bin + 1) < (unsigned)WINDOW_WIDTH;
                         const bool c0 = (unsigned)col_bin < (unsigned)WINDOW_WIDTH;
                         const bool c1 = (unsigned)(col_bin + 1) < (unsigned)WINDOW_WIDTH;
+                        if constexpr (COUNT) {
+                            n_samples += 1;
+                            n_atomics += 2 * (((int)r0 + (int)r1) * ((int)c0 + (int)c1));
+                            continue;
+                        }
                         if (r0 && c0) {
                             const double hi = m00 * ori_pr;
                             atomicAdd(cell + ob0, m00 - hi);
@@ -235,6 +247,20 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                     }
                 }
             }
+        }
+        if constexpr (COUNT) {
+            // wave totals (fewer than 2^32 per keypoint), then one 64-bit add per wave
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                n_samples += __shfl_xor(n_samples, sft);
+                n_atomics += __shfl_xor(n_atomics, sft);
+            }
+            if (lane == 0) {
+                atomicAdd(&work[2 * f], (unsigned long long)n_samples);
+                atomicAdd(&work[2 * f + 1], (unsigned long long)n_atomics);
+            }
+            n_samples = n_atomics = 0;
+            __syncthreads();
+            continue;
         }
         __syncthreads();
         // inner 4x4x8 bins (sift.cpp:557-563), copies summed in fixed order
@@ -276,7 +302,14 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
 void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
                         const FrameCounters *counters, int32_t *cursors, uint8_t *desc) {
     dim3 grid(2048 / NWAVES, nframes);
-    hipLaunchKernelGGL(k_descriptors, grid, dim3(NT), 0, st, p, kps, kp_cap, counters, cursors, desc);
+    hipLaunchKernelGGL(k_descriptors<false>, grid, dim3(NT), 0, st, p, kps, kp_cap, counters, cursors, desc,
+                       (unsigned long long *)nullptr);
+}
+
+void launch_descriptor_work(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
+                            const FrameCounters *counters, int32_t *cursors, unsigned long long *work) {
+    dim3 grid(2048 / NWAVES, nframes);
+    hipLaunchKernelGGL(k_descriptors<true>, grid, dim3(NT), 0, st, p, kps, kp_cap, counters, cursors, (uint8_t *)nullptr, work);
 }
 
 }  // namespace sa

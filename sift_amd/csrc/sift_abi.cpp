@@ -11,26 +11,24 @@
 #include <string>
 #include <vector>
 
-#include "common.h"
-#include "kernels.h"
+#include "abi_internal.h"
 
 using namespace sa;
 
-namespace {
+namespace sa {
 
+namespace {
 thread_local std::string g_last_error;
+}
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
 
-#define HIP_TRY(expr)                                                                           \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail(SIFT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
-    } while (0)
+}  // namespace sa
+
+namespace {
 
 // cvRound: round half to even
 int cv_round(double v) { return (int)std::lrint(v); }
@@ -65,49 +63,6 @@ int gaussian_taps(double sigma, Taps &taps) {
 }
 
 }  // namespace
-
-struct sift_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    void *knn_scratch = nullptr;
-    size_t knn_scratch_bytes = 0;
-    void *knn_static = nullptr;  // this device's copy of the matcher's file-scope scratch array (sift_knn2_device_noalloc)
-    void *knn_io = nullptr;  // device staging of the host-buffer matcher calls
-    size_t knn_io_bytes = 0;
-    void *h_work = nullptr;  // device workspace of sift_find_homography
-    size_t h_work_bytes = 0;
-    void *st_work = nullptr;  // device workspace of the composition calls
-    size_t st_work_bytes = 0;
-    hipStream_t aux = nullptr;              // second stream of the small-workload schedule (run_pipeline)
-    hipEvent_t oct_ready[MAX_OCTAVES] = {};  // level 3 of octave o is complete
-    hipEvent_t aux_done = nullptr;
-    void *pinned = nullptr;  // page-locked host staging of the single-image calls and of result downloads
-    size_t pinned_bytes = 0;
-    sift_batch *cached = nullptr;  // workspace of the single-image calls
-    int single_cap = 0;            // its initial per-frame list capacity (0: the batch default)
-};
-
-struct sift_batch {
-    sift_ctx *ctx = nullptr;
-    int w = 0, h = 0, max_frames = 0;
-    Pyramid pyr{};
-    uint8_t *d_frames = nullptr;
-    const uint8_t *d_ext_frames = nullptr;  // caller-owned frames, if set
-    uint8_t *d_bgr = nullptr;  // one frame of BGR staging, allocated on first use
-    Candidate *d_cand = nullptr;
-    int cand_cap = 0;
-    DevKeypoint *d_oriented = nullptr, *d_sorted = nullptr, *d_final = nullptr;
-    uint8_t *d_flags = nullptr;
-    int kp_cap = 0;
-    uint8_t *d_desc = nullptr;
-    FrameCounters *d_counters = nullptr;
-    int32_t *d_cursors = nullptr;  // [3][max_frames]: (unused), descriptor cursor, localised count
-    Taps base_taps{};
-    int base_ntaps = 0;
-    Taps lvl_taps[IMAGES]{};
-    int lvl_ntaps[IMAGES]{};
-    std::vector<hipEvent_t> events;
-};
 
 // Page-locked staging: copies between pageable user memory and the device go through it, because the runtime
 // otherwise pins and unpins the user's pages on every call (milliseconds for a frame or a descriptor block).
@@ -254,6 +209,7 @@ int sift_batch_destroy(sift_batch *b) {
     hipFree(b->d_desc);
     hipFree(b->d_counters);
     hipFree(b->d_cursors);
+    hipFree(b->d_work);
     for (hipEvent_t e : b->events) hipEventDestroy(e);
     if (b->ctx->cached == b) b->ctx->cached = nullptr;
     delete b;
@@ -406,7 +362,9 @@ struct StageTimer {
     }
 };
 
-int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
+}  // namespace
+
+int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
     sift_ctx *ctx = b->ctx;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -472,8 +430,6 @@ int run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
     }
     return SIFT_OK;
 }
-
-}  // namespace
 
 extern "C" {
 
@@ -542,6 +498,24 @@ int sift_batch_download(sift_batch *b, int frame, int capacity, sift_keypoint *k
         if (desc_f64)
             for (size_t i = 0; i < desc_bytes; i++) desc_f64[i] = (double)src[i];
     }
+    return SIFT_OK;
+}
+
+int sift_batch_descriptor_work(sift_batch *b, int n_frames, int64_t *work) {
+    if (!b || !work) return fail(SIFT_ERR_INVALID, "NULL argument");
+    if (n_frames < 1 || n_frames > b->max_frames) return fail(SIFT_ERR_INVALID, "n_frames out of range");
+    sift_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n_frames * 2 * sizeof(unsigned long long);
+    if (!b->d_work) HIP_TRY(hipMalloc((void **)&b->d_work, (size_t)b->max_frames * 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(b->d_work, 0, bytes, ctx->stream));
+    HIP_TRY(hipMemsetAsync(b->d_cursors + b->max_frames, 0, (size_t)b->max_frames * sizeof(int32_t), ctx->stream));
+    launch_descriptor_work(ctx->stream, b->pyr, n_frames, b->d_final, b->kp_cap, b->d_counters, b->d_cursors + b->max_frames,
+                           b->d_work);
+    HIP_TRY(hipGetLastError());
+    static_assert(sizeof(int64_t) == sizeof(unsigned long long), "layout");
+    HIP_TRY(hipMemcpyAsync(work, b->d_work, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SIFT_OK;
 }
 
@@ -709,7 +683,9 @@ int sift_result_get_f32(const sift_result *r, float *out) {
 
 // ---- matcher ----------------------------------------------------------------
 
-static int ensure_bytes(void **buf, size_t *have, size_t want) {
+}  // extern "C"
+
+int sa::ensure_bytes(void **buf, size_t *have, size_t want) {
     if (*have >= want) return SIFT_OK;
     if (*buf) {
         hipError_t e = hipFree(*buf);
@@ -721,6 +697,8 @@ static int ensure_bytes(void **buf, size_t *have, size_t want) {
     *have = want;
     return SIFT_OK;
 }
+
+extern "C" {
 
 int sift_knn2_device(sift_ctx *ctx, const void *d_q, int nq, const void *d_t, int nt, int train_index_base,
                      void *d_out) {

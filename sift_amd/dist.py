@@ -33,6 +33,9 @@ def _hip_local_knn(ctx):
 
     def run(q, t, train_base):
         out = torch.empty((q.shape[0], 4), dtype=torch.int32, device=q.device)
+        # q and t may have been produced by torch work that is still in flight on torch's stream (a cast, a slice, a
+        # receive), and the context launches on a stream of its own
+        torch.cuda.current_stream().synchronize()
         ctx.knn2_device(q.data_ptr(), q.shape[0], t.data_ptr() if t.shape[0] else 0, t.shape[0], train_base,
                         out.data_ptr())
         ctx.synchronize()

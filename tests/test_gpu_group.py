@@ -1,0 +1,104 @@
+"""GPU tests of the single-process multi-GPU entry points (sift_group_*): on a one-GPU box the group has one member,
+which still takes the whole path -- RCCL communicator, grouped send/receive of the query slices (to itself), merge,
+the double-buffered host-to-host extraction pipeline -- and must reproduce the single-context calls bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def group(sift_lib, ctx):
+    g = sift_lib.Group([ctx])
+    yield g
+    g.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (101, 1000), (5000, 33000), (7, 0)])
+def test_sharded_matcher_equals_the_single_context_one(sift_lib, ctx, group, oracle, nq, nt):
+    t = sift_lib.synth_descriptors(5, nt)
+    q = sift_lib.synth_queries(6, t, nq) if nt else np.zeros((nq, 128), np.uint8)
+    want, wacc = ctx.knn2(q, t)
+    got, gacc = group.knn2(q, t)
+    assert np.array_equal(got, want) and np.array_equal(gacc, wacc)
+    if nt:
+        i1, d1, i2, d2, oacc = oracle.knn2_u8(q, t, threads=16)
+        assert np.array_equal(got["i1"], i1) and np.array_equal(got["d1"], d1)
+        assert np.array_equal(got["i2"], i2) and np.array_equal(got["d2"], d2) and np.array_equal(gacc, oacc)
+
+
+def test_sharded_matcher_rejects_bytes_above_127(sift_lib, group):
+    with pytest.raises(sift_lib.SiftError) as e:
+        group.knn2(np.full((4, 128), 128, np.uint8), np.zeros((4, 128), np.uint8))
+    assert e.value.code == sift_lib.api.SIFT_ERR_NOT_INTEGRAL
+
+
+def test_batch_extraction_from_host_frames_equals_single_calls(sift_lib, ctx, group):
+    w, h, n = 320, 240, 7
+    frames = np.stack([sift_lib.synth_dead_leaves(7, i, w, h) for i in range(n)])
+    want = [ctx.extract(f) for f in frames]
+    for per_launch in (3, 16):          # chunks of 3, 3, 1 through both workspaces; then one chunk
+        got = group.extract_batch(frames, per_launch)
+        assert len(got) == n
+        for (kp, desc, info), (wkp, wdesc, winfo) in zip(got, want):
+            assert np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
+            assert info["candidates"] == winfo["candidates"] and info["keypoints"] == winfo["keypoints"]
+    # rows and frames with padding between them
+    padded = np.zeros((n, h + 3, w + 5), np.uint8)
+    padded[:, :h, :w] = frames
+    import ctypes as C
+    res = (sift_lib.api._FrameResult * n)()
+    rc = sift_lib.lib().sift_extract_batch_u8(group._h, padded.ctypes.data, n, w, h, padded.strides[1], padded.strides[0], 4, res)
+    assert rc == 0
+    for r, (wkp, wdesc, _) in zip(res, want):
+        assert r.n == len(wkp)
+        d = np.ctypeslib.as_array(C.cast(r.descriptors, C.POINTER(C.c_uint8)), (r.n, 128))
+        assert np.array_equal(d, wdesc.astype(np.uint8))
+    sift_lib.lib().sift_frame_results_free(res, n)
+
+
+def test_batch_extraction_reruns_frames_that_overflow_their_lists(sift_lib, ctx, oracle, lenna_bgr):
+    gray = oracle.bgr_to_gray(lenna_bgr)
+    frames = np.stack([gray, gray[::-1].copy()])
+    want = [ctx.extract(f) for f in frames]
+    g = sift_lib.Group([ctx])
+    try:
+        ctx.set_single_image_capacity(64)          # also the list capacity of the group's workspaces
+        got = g.extract_batch(frames, 2)
+        for (kp, desc, _), (wkp, wdesc, _) in zip(got, want):
+            assert len(kp) > 64 and np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
+    finally:
+        ctx.set_single_image_capacity(0)
+        g.close()
+
+
+def test_sharded_knn2_over_a_one_rank_rccl_group(sift_lib, ctx, oracle):
+    """sift_amd.dist.sharded_knn2 with its default HIP search and merge inside a real `nccl` process group (one rank
+    here): all_to_all_single and all_gather over RCCL, query count not a multiple of the slice."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from sift_amd.dist import sharded_knn2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29641")
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        nq, nt = 1001, 20000
+        t = sift_lib.synth_descriptors(5, nt)
+        q = sift_lib.synth_queries(6, t, nq)
+        i1, d1, i2, d2, oacc = oracle.knn2_u8(q, t, threads=16)
+        # operands produced by asynchronous torch work right before the call
+        d_t = torch.from_numpy(t).cuda().to(torch.int32).to(torch.uint8)
+        d_q = torch.from_numpy(q).cuda().to(torch.int32).to(torch.uint8)
+        for gather in (True, False):
+            knn, acc, (lo, hi) = sharded_knn2(d_q, d_t, 0, ctx=ctx, gather=gather)
+            k = knn.cpu().numpy()
+            assert (lo, hi) == (0, nq)
+            assert np.array_equal(k[:, 0], d1) and np.array_equal(k[:, 1], i1)
+            assert np.array_equal(k[:, 2], d2) and np.array_equal(k[:, 3], i2)
+            assert np.array_equal(acc.cpu().numpy(), oacc)
+    finally:
+        if started:
+            dist.destroy_process_group()
