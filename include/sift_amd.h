@@ -88,6 +88,15 @@ int sift_octave_dims(int w, int h, int oct, int *ow, int *oh);
  * (sift.cpp:29); sift_extract_gray8 starts after it.  stride is in bytes. */
 int sift_extract_gray8(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, sift_result *out);
 int sift_extract_bgr8(sift_ctx *ctx, const uint8_t *bgr, int w, int h, size_t stride, sift_result *out);
+/* sift_extract_gray8 that also reports the device time of the five stages the reference times with TIMEIT in exec()
+ * (sift.cpp:71,72,86,87,92), in milliseconds: gen_gaussian_images, gen_dog_images (always 0: the differences are never
+ * stored), gen_scale_space_extrema, clean_keypoints, get_descriptors.  The schedule is that of sift_extract_gray8; the
+ * times come from five events at the stage boundaries of the main stream. */
+int sift_extract_gray8_stages(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, sift_result *out,
+                              double stage_ms[5]);
+/* The base image the constructor builds (sift.cpp:40-45): the gray frame upsampled x2 (INTER_LINEAR) and blurred
+ * with sigma sqrt(1.6^2 - 4*0.5^2); base receives 2h rows of 2w doubles. */
+int sift_base_image_gray8(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, double *base);
 int sift_result_free(sift_result *r);
 /* get() (sift.hpp:27, sift.cpp:103-112): n x 128 float32 copy of the descriptors. */
 int sift_result_get_f32(const sift_result *r, float *out);

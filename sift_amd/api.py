@@ -34,7 +34,7 @@ COUNTS_DTYPE = np.dtype([("candidates", "<i4"), ("oriented", "<i4"), ("keypoints
 # every symbol include/sift_amd.h declares
 EXPORTED_SYMBOLS = (
     "sift_last_error", "sift_device_count", "sift_ctx_create", "sift_ctx_destroy", "sift_ctx_stream",
-    "sift_ctx_synchronize", "sift_ctx_set_single_image_capacity", "sift_num_octaves", "sift_octave_dims", "sift_extract_gray8", "sift_extract_bgr8",
+    "sift_ctx_synchronize", "sift_ctx_set_single_image_capacity", "sift_num_octaves", "sift_octave_dims", "sift_extract_gray8", "sift_extract_bgr8", "sift_extract_gray8_stages", "sift_base_image_gray8",
     "sift_result_free", "sift_result_get_f32", "sift_batch_create", "sift_batch_destroy",
     "sift_batch_frames_device_ptr", "sift_batch_set_external_frames", "sift_batch_upload_gray8", "sift_batch_upload_bgr8", "sift_batch_run",
     "sift_batch_counts", "sift_batch_download", "sift_batch_result_device_ptrs", "sift_batch_get_level",
@@ -121,6 +121,8 @@ def lib():
     L.sift_octave_dims.argtypes = [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
     L.sift_extract_gray8.argtypes = [vp, vp, ci, ci, sz, C.POINTER(_Result)]
     L.sift_extract_bgr8.argtypes = [vp, vp, ci, ci, sz, C.POINTER(_Result)]
+    L.sift_extract_gray8_stages.argtypes = [vp, vp, ci, ci, sz, C.POINTER(_Result), C.POINTER(C.c_double)]
+    L.sift_base_image_gray8.argtypes = [vp, vp, ci, ci, sz, vp]
     L.sift_result_free.argtypes = [C.POINTER(_Result)]
     L.sift_result_get_f32.argtypes = [C.POINTER(_Result), vp]
     L.sift_batch_create.argtypes = [vp, ci, ci, ci, ci, pvp]
@@ -279,6 +281,32 @@ class Context:
         finally:
             lib().sift_result_free(C.byref(res))
         return kps, desc, info
+
+    def base_image(self, gray):
+        """The constructor's base image (sift.cpp:40-45) of an HxW uint8 frame: 2H x 2W float64."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        out = np.empty((2 * h, 2 * w), np.float64)
+        _check(lib().sift_base_image_gray8(self._h, gray.ctypes.data, w, h, gray.strides[0], out.ctypes.data))
+        return out
+
+    def extract_stages(self, gray):
+        """extract() of a gray frame plus the device milliseconds of the reference's five TIMEIT stages."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        res = _Result()
+        ms = (C.c_double * 5)()
+        _check(lib().sift_extract_gray8_stages(self._h, gray.ctypes.data, w, h, gray.strides[0], C.byref(res), ms))
+        try:
+            n = res.n
+            kps = np.zeros(n, KEYPOINT_DTYPE)
+            desc = np.zeros((n, 128), np.float64)
+            if n:
+                C.memmove(kps.ctypes.data, res.keypoints, n * KEYPOINT_DTYPE.itemsize)
+                C.memmove(desc.ctypes.data, res.descriptors, n * 128 * 8)
+        finally:
+            lib().sift_result_free(C.byref(res))
+        return kps, desc, list(ms)
 
     def batch(self, w, h, max_frames, max_keypoints_per_frame=0):
         return Batch(self, w, h, max_frames, max_keypoints_per_frame)

@@ -41,6 +41,7 @@ struct sift_ctx {
     hipStream_t aux = nullptr;              // second stream of the small-workload schedule (run_pipeline)
     hipEvent_t oct_ready[sa::MAX_OCTAVES] = {};  // level 3 of octave o is complete
     hipEvent_t aux_done = nullptr;
+    hipEvent_t group_ev[5] = {};  // timing events at the reference's stage boundaries (run_pipeline's `group_ms`)
     void *pinned = nullptr;  // page-locked host staging of the single-image calls and of result downloads
     size_t pinned_bytes = 0;
     sift_batch *cached = nullptr;  // workspace of the single-image calls
@@ -73,7 +74,11 @@ struct sift_batch {
 namespace sa {
 
 // exec() (sift.cpp:67-98) for frames [0, n) of a batch as a sequence of launches on the context stream;
-// `times` (may be null) receives per-stage device times and serialises the run.
-int run_pipeline(sift_batch *b, int n, sift_stage_times *times);
+// `times` (may be null) receives per-kernel-stage device times and serialises the run.  `group_ms` (may be null;
+// ignored with `times`) makes the run record five events at the boundaries of the reference's TIMEIT stages
+// (sift.cpp:71,72,86,87,92) without changing the schedule; read them with pipeline_group_times after the stream
+// has been synchronised.
+int run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_events = false);
+int pipeline_group_times(sift_ctx *ctx, double ms[5]);
 
 }  // namespace sa

@@ -144,6 +144,8 @@ int sift_ctx_destroy(sift_ctx *ctx) {
     for (hipEvent_t e : ctx->oct_ready)
         if (e) hipEventDestroy(e);
     if (ctx->aux_done) hipEventDestroy(ctx->aux_done);
+    for (hipEvent_t e : ctx->group_ev)
+        if (e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SIFT_OK;
@@ -364,7 +366,40 @@ struct StageTimer {
 
 }  // namespace
 
-int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
+// Second stream and its events, created together: the context keeps them only if every creation succeeded.
+static int ensure_aux(sift_ctx *ctx) {
+    if (ctx->aux) return SIFT_OK;
+    hipStream_t aux = nullptr;
+    hipEvent_t ready[MAX_OCTAVES] = {};
+    hipEvent_t done = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+    for (int i = 0; i < MAX_OCTAVES && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        for (hipEvent_t ev : ready)
+            if (ev) hipEventDestroy(ev);
+        if (done) hipEventDestroy(done);
+        if (aux) hipStreamDestroy(aux);
+        return fail(SIFT_ERR_HIP, std::string("second stream set-up: ") + hipGetErrorString(e));
+    }
+    for (int i = 0; i < MAX_OCTAVES; i++) ctx->oct_ready[i] = ready[i];
+    ctx->aux_done = done;
+    ctx->aux = aux;
+    return SIFT_OK;
+}
+
+int sa::pipeline_group_times(sift_ctx *ctx, double ms[5]) {
+    float t[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&t[i], ctx->group_ev[i], ctx->group_ev[i + 1]));
+    ms[0] = t[0];  // gen_gaussian_images (base blur included: the constructor's share is not separable from the launch order)
+    ms[1] = 0.0;   // gen_dog_images: no such pass, the differences are formed in registers by their readers
+    ms[2] = t[1];  // gen_scale_space_extrema
+    ms[3] = t[2];  // clean_keypoints
+    ms[4] = t[3];  // get_descriptors
+    return SIFT_OK;
+}
+
+int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_events) {
     sift_ctx *ctx = b->ctx;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -384,38 +419,53 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times) {
     // of each finished octave: about half as many launches on the critical path.  Large batches keep the plain order
     // (their launches fill the chip, and the profiled pass times each launch on its own).
     const bool two_streams = !times && (int64_t)n * b->w * b->h <= ((int64_t)1 << 22);
+    group_events = group_events && !times;
+    if (group_events) {
+        for (hipEvent_t &e : ctx->group_ev)
+            if (!e) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(ctx->group_ev[0], st));
+    }
     if (two_streams) {
-        if (!ctx->aux) {
-            HIP_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-            for (hipEvent_t &e : ctx->oct_ready) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->aux_done, hipEventDisableTiming));
-        }
+        int rc = ensure_aux(ctx);
+        if (rc) return rc;
         hipStream_t aux = ctx->aux;
+        // Once the second stream has work, every way out of this block joins it first: later calls on the main
+        // stream must not overlap kernels that are still writing the pyramid and the candidate lists.
+        hipError_t e = hipSuccess;
         launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps);
-        for (int o = 0; o < b->pyr.octaves; o++) {
+        for (int o = 0; o < b->pyr.octaves && e == hipSuccess; o++) {
             for (int lvl = 1; lvl <= IMAGES - 3; lvl++) launch_blur(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
-            HIP_TRY(hipEventRecord(ctx->oct_ready[o], st));
-            HIP_TRY(hipStreamWaitEvent(aux, ctx->oct_ready[o], 0));
+            if ((e = hipEventRecord(ctx->oct_ready[o], st)) != hipSuccess) break;
+            if ((e = hipStreamWaitEvent(aux, ctx->oct_ready[o], 0)) != hipSuccess) break;
             for (int lvl = IMAGES - 2; lvl < IMAGES; lvl++) launch_blur(aux, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
             launch_extrema_gradients(aux, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters);
         }
-        HIP_TRY(hipEventRecord(ctx->aux_done, aux));
-        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_done, 0));
+        if (e == hipSuccess && group_events) e = hipEventRecord(ctx->group_ev[1], st);
+        if (e == hipSuccess) e = hipEventRecord(ctx->aux_done, aux);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->aux_done, 0);
+        if (e != hipSuccess) {
+            hipStreamSynchronize(aux);
+            return fail(SIFT_ERR_HIP, std::string("two-stream schedule: ") + hipGetErrorString(e));
+        }
     } else {
         TIMED(SIFT_STAGE_BASE, launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
         for (int o = 0; o < b->pyr.octaves; o++)
             for (int lvl = 1; lvl < IMAGES; lvl++)
                 TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
+        if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[1], st));
         for (int o = 0; o < b->pyr.octaves; o++)
             if (b->pyr.grad[o])
                 TIMED(SIFT_STAGE_EXTREMA, launch_extrema_gradients(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
     }
     TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_sorted, b->d_oriented,
                                                       b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames));
+    if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[2], st));
     TIMED(SIFT_STAGE_CLEAN,
           launch_clean(st, n, b->d_oriented, b->d_sorted, b->d_final, b->d_flags, b->kp_cap, b->d_counters));
+    if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[3], st));
     TIMED(SIFT_STAGE_DESCRIPTOR, launch_descriptors(st, b->pyr, n, b->d_final, b->kp_cap, b->d_counters,
                                                     b->d_cursors + b->max_frames, b->d_desc));
+    if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[4], st));
 #undef TIMED
     HIP_TRY(hipGetLastError());
     if (times) {
@@ -593,7 +643,43 @@ int sift_batch_get_oriented(sift_batch *b, int frame, int capacity, sift_keypoin
 
 // ---- single image ---------------------------------------------------------
 
-static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, bool bgr, sift_result *out) {
+// The single-image workspace of a context for w x h frames, created or grown on demand.
+static int single_workspace(sift_ctx *ctx, int w, int h, int want_cap, bool must_grow, sift_batch **out) {
+    sift_batch *b = ctx->cached;
+    if (!b || b->w != w || b->h != h || (must_grow && b->kp_cap < want_cap)) {
+        if (b) sift_batch_destroy(b);
+        ctx->cached = nullptr;
+        int rc = sift_batch_create(ctx, w, h, 1, want_cap, &b);
+        if (rc) return rc;
+        ctx->cached = b;
+    }
+    *out = b;
+    return SIFT_OK;
+}
+
+// One host frame into slot 0 of a workspace through the page-locked staging buffer.
+static int upload_single(sift_ctx *ctx, sift_batch *b, const uint8_t *img, size_t stride, bool bgr) {
+    const int w = b->w, h = b->h;
+    const size_t row_bytes = (size_t)w * (bgr ? 3 : 1);
+    if (stride < row_bytes) return fail(SIFT_ERR_INVALID, "stride smaller than a row");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *stage = nullptr;
+    int rc = stage_in(ctx, row_bytes * h, &stage);
+    if (rc) return rc;
+    for (int y = 0; y < h; y++) std::memcpy(static_cast<char *>(stage) + row_bytes * y, img + stride * y, row_bytes);
+    if (bgr) {
+        if (!b->d_bgr) HIP_TRY(hipMalloc((void **)&b->d_bgr, row_bytes * h));
+        HIP_TRY(hipMemcpyAsync(b->d_bgr, ctx->pinned, row_bytes * h, hipMemcpyHostToDevice, ctx->stream));
+        launch_bgr_to_gray(ctx->stream, b->d_bgr, b->d_frames, (size_t)w * h);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(b->d_frames, ctx->pinned, row_bytes * h, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return SIFT_OK;
+}
+
+static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_t stride, bool bgr, sift_result *out,
+                          double *stage_ms = nullptr) {
     if (!ctx || !img || !out) return fail(SIFT_ERR_INVALID, "NULL argument");
     std::memset(out, 0, sizeof(*out));
     // The reference's lists grow without bound; here a frame whose candidates or keypoints exceed the
@@ -602,31 +688,11 @@ static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_
     sift_frame_counts fc;
     int want_cap = ctx->single_cap;
     for (int attempt = 0;; attempt++) {
-        b = ctx->cached;
-        if (!b || b->w != w || b->h != h || (attempt > 0 && b->kp_cap < want_cap)) {
-            if (b) sift_batch_destroy(b);
-            ctx->cached = nullptr;
-            int rc = sift_batch_create(ctx, w, h, 1, want_cap, &b);
-            if (rc) return rc;
-            ctx->cached = b;
-        }
-        // the frame goes up through page-locked staging
-        const size_t row_bytes = (size_t)w * (bgr ? 3 : 1);
-        if (stride < row_bytes) return fail(SIFT_ERR_INVALID, "stride smaller than a row");
-        HIP_TRY(hipSetDevice(ctx->device));
-        void *stage = nullptr;
-        int rc = stage_in(ctx, row_bytes * h, &stage);
+        int rc = single_workspace(ctx, w, h, want_cap, attempt > 0, &b);
         if (rc) return rc;
-        for (int y = 0; y < h; y++) std::memcpy(static_cast<char *>(stage) + row_bytes * y, img + stride * y, row_bytes);
-        if (bgr) {
-            if (!b->d_bgr) HIP_TRY(hipMalloc((void **)&b->d_bgr, row_bytes * h));
-            HIP_TRY(hipMemcpyAsync(b->d_bgr, ctx->pinned, row_bytes * h, hipMemcpyHostToDevice, ctx->stream));
-            launch_bgr_to_gray(ctx->stream, b->d_bgr, b->d_frames, (size_t)w * h);
-            HIP_TRY(hipGetLastError());
-        } else {
-            HIP_TRY(hipMemcpyAsync(b->d_frames, ctx->pinned, row_bytes * h, hipMemcpyHostToDevice, ctx->stream));
-        }
-        if ((rc = sift_batch_run(b, 1))) return rc;
+        if ((rc = upload_single(ctx, b, img, stride, bgr))) return rc;
+        b->d_ext_frames = nullptr;
+        if ((rc = run_pipeline(b, 1, nullptr, stage_ms != nullptr))) return rc;
         rc = sift_batch_counts(b, 1, &fc);
         if (rc == SIFT_ERR_OVERFLOW && attempt < 4) {
             const int64_t seen = std::max<int64_t>(std::max(fc.candidates, fc.oriented), b->kp_cap);
@@ -636,6 +702,10 @@ static int extract_common(sift_ctx *ctx, const uint8_t *img, int w, int h, size_
         }
         if (rc) return rc;
         break;
+    }
+    if (stage_ms) {
+        int rc = pipeline_group_times(ctx, stage_ms);  // the stream was synchronised by sift_batch_counts
+        if (rc) return rc;
     }
     out->counts = fc;
     out->octaves = b->pyr.octaves;
@@ -663,6 +733,23 @@ int sift_extract_gray8(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t 
 
 int sift_extract_bgr8(sift_ctx *ctx, const uint8_t *bgr, int w, int h, size_t stride, sift_result *out) {
     return extract_common(ctx, bgr, w, h, stride, true, out);
+}
+
+int sift_extract_gray8_stages(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, sift_result *out,
+                              double stage_ms[5]) {
+    if (!stage_ms) return fail(SIFT_ERR_INVALID, "stage_ms is NULL");
+    return extract_common(ctx, gray, w, h, stride, false, out, stage_ms);
+}
+
+int sift_base_image_gray8(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, double *base) {
+    if (!ctx || !gray || !base) return fail(SIFT_ERR_INVALID, "NULL argument");
+    sift_batch *b = nullptr;
+    int rc = single_workspace(ctx, w, h, ctx->single_cap, false, &b);
+    if (rc) return rc;
+    if ((rc = upload_single(ctx, b, gray, stride, false))) return rc;
+    launch_base(ctx->stream, b->d_frames, b->w, b->h, 1, b->pyr, b->base_taps, b->base_ntaps);
+    HIP_TRY(hipGetLastError());
+    return sift_batch_get_level(b, 0, 0, 0, SIFT_LEVEL_GAUSS, base);
 }
 
 int sift_result_free(sift_result *r) {

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <ostream>
 #include <vector>
 
@@ -47,6 +48,58 @@ struct KeyPoint {
         : pt(x, y), size(size_), angle(angle_), response(response_), octave(octave_), class_id(class_id_) {}
 };
 
+// Large matrix blocks are recycled: a fresh 66 MB allocation (the base image of a 1080p frame) is mapped and
+// page-faulted by the kernel every time, which costs several times the GPU work of the frame; a released block is
+// kept (up to 512 MB in all) and handed to the next matrix of at most its size.
+namespace detail {
+struct BlockCache {
+    struct Block {
+        unsigned char *p;
+        size_t bytes;
+    };
+    std::mutex mu;
+    std::vector<Block> blocks;
+    size_t held = 0;
+    static constexpr size_t kMinBytes = (size_t)1 << 20, kMaxHeld = (size_t)512 << 20;
+    static BlockCache &get() {
+        static BlockCache c;
+        return c;
+    }
+    unsigned char *take(size_t bytes, size_t *got) {
+        if (bytes >= kMinBytes) {
+            std::lock_guard<std::mutex> lock(mu);
+            size_t best = blocks.size();
+            for (size_t i = 0; i < blocks.size(); i++)
+                if (blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
+                    best = i;
+            if (best != blocks.size()) {
+                const Block b = blocks[best];
+                blocks.erase(blocks.begin() + (std::ptrdiff_t)best);
+                held -= b.bytes;
+                *got = b.bytes;
+                return b.p;
+            }
+        }
+        *got = bytes;
+        return new unsigned char[bytes];
+    }
+    void give(unsigned char *p, size_t bytes) {
+        if (bytes >= kMinBytes) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (held + bytes <= kMaxHeld) {
+                blocks.push_back(Block{p, bytes});
+                held += bytes;
+                return;
+            }
+        }
+        delete[] p;
+    }
+    ~BlockCache() {
+        for (const Block &b : blocks) delete[] b.p;
+    }
+};
+}  // namespace detail
+
 // Dense 2-D matrix with reference-counted storage (the subset of cv::Mat used
 // around sift_handler: construction, at<>, ptr<>, clone, release, size, type).
 class Mat {
@@ -68,8 +121,9 @@ class Mat {
         type_ = type;
         step = (size_t)c * elemSize();
         // contents are indeterminate, as with cv::Mat::create
-        store_ = std::shared_ptr<unsigned char>(new unsigned char[step * (size_t)(r > 0 ? r : 1)],
-                                               std::default_delete<unsigned char[]>());
+        size_t got = 0;
+        unsigned char *block = detail::BlockCache::get().take(step * (size_t)(r > 0 ? r : 1), &got);
+        store_ = std::shared_ptr<unsigned char>(block, [got](unsigned char *q) { detail::BlockCache::get().give(q, got); });
         data = store_.get();
     }
     int type() const { return type_; }

@@ -4,6 +4,7 @@
 #include "sift.hpp"
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -32,27 +33,9 @@ sift_ctx *context() {
     return ctx;
 }
 
-// The pyramid workspace of the last frame size, kept between exec() calls (allocating and freeing it costs more
-// than running a frame through it).  The library is used from one thread at a time, as the reference is.
-// `min_capacity` (keypoints per frame, 0 = the library's default) only ever grows the workspace.
-sift_batch *workspace(int w, int h, int min_capacity) {
-    static sift_batch *batch = nullptr;
-    static int bw = 0, bh = 0, cap = 0;
-    if (!batch || bw != w || bh != h || cap < min_capacity) {
-        if (batch) sift_batch_destroy(batch);
-        batch = nullptr;
-        check(sift_batch_create(context(), w, h, 1, min_capacity, &batch), "sift_batch_create");
-        bw = w;
-        bh = h;
-        cap = min_capacity;
-    }
-    return batch;
-}
-
 }  // namespace
 
-// sift.cpp:26-46: gray conversion, onex, octave count; the 2x upsample and base
-// blur happen on the GPU inside exec().
+// sift.cpp:26-46: gray conversion, onex, octave count, and the base image (2x upsample + blur, on the GPU).
 sift_handler::sift_handler(std::string _name, cv::Mat &&_base) : name(std::move(_name)) {
     if (_base.empty() || _base.depth() != CV_8U || (_base.channels() != 3 && _base.channels() != 1))
         throw std::runtime_error("sift_handler: expected an 8-bit BGR or gray image");
@@ -72,11 +55,18 @@ sift_handler::sift_handler(std::string _name, cv::Mat &&_base) : name(std::move(
     }
     _base.release();  // sift.cpp:32
     onex = cv::Mat(height_, width_, CV_64FC1);  // sift.cpp:30, :33
-    for (int y = 0; y < height_; y++)
-        for (int x = 0; x < width_; x++) onex.at<double>(y, x) = gray_[(size_t)y * width_ + x];
+    for (int y = 0; y < height_; y++) {
+        double *dst = onex.ptr<double>(y);
+        const unsigned char *src = gray_.data() + (size_t)y * width_;
+        for (int x = 0; x < width_; x++) dst[x] = src[x];
+    }
     octaves = sift_num_octaves(width_, height_);  // sift.cpp:36
     std::cerr << "Octaves: " << octaves << std::endl;
     std::cerr << "Size: " << cv::Size(width_, height_) << std::endl;
+    base = cv::Mat(2 * height_, 2 * width_, CV_64FC1);  // sift.cpp:40-45
+    if (base.step != (size_t)2 * width_ * sizeof(double)) throw std::runtime_error("sift_handler: unexpected row padding");
+    check(sift_base_image_gray8(context(), gray_.data(), width_, height_, (size_t)width_, base.ptr<double>(0)),
+          "sift_base_image_gray8");
 }
 
 sift_handler::~sift_handler() {
@@ -89,50 +79,26 @@ sift_handler::~sift_handler() {
 // sift.cpp:67-98
 void sift_handler::exec() {
     std::cerr << "Running SIFT for " << name << "\n";
-    sift_batch *batch = nullptr;
-    sift_stage_times t;
-    sift_frame_counts counts;
-    // keypoints and descriptors are unbounded vectors in the reference (sift.hpp:93-94): a frame that overflows
-    // the workspace is run again in a larger one
-    for (int capacity = 0, attempt = 0;; attempt++) {
-        batch = workspace(width_, height_, capacity);
-        check(sift_batch_upload_gray8(batch, 0, gray_.data(), (size_t)width_), "sift_batch_upload_gray8");
-        check(sift_batch_run_profiled(batch, 1, &t), "sift_batch_run_profiled");
-        const int rc = sift_batch_counts(batch, 1, &counts);
-        if (rc == SIFT_ERR_OVERFLOW && attempt < 4) {
-            capacity = 2 * std::max({counts.candidates, counts.oriented, 8192, width_ * height_ / 16});
-            continue;
-        }
-        check(rc, "sift_batch_counts");
-        break;
+    // the whole of exec() is one library call on the fast single-image schedule; keypoints and descriptors are
+    // unbounded vectors in the reference (sift.hpp:93-94), and the call grows its workspace when a frame needs it
+    sift_result res;
+    double ms[5];
+    check(sift_extract_gray8_stages(context(), gray_.data(), width_, height_, (size_t)width_, &res, ms),
+          "sift_extract_gray8_stages");
+    // the reference's five TIMEIT stages (sift.cpp:71,72,86,87,92)
+    static const char *const stage[5] = {"gen_gaussian_images", "gen_dog_images", "gen_scale_space_extrema", "clean_keypoints",
+                                         "get_descriptors"};
+    for (int i = 0; i < 5; i++) std::cerr << "elapsed time: " << stage[i] << ": " << 1e-3 * ms[i] << "s\n";
+    keypoints.clear();
+    descriptors.clear();
+    keypoints.reserve((size_t)res.n);
+    descriptors.reserve((size_t)res.n);
+    for (int i = 0; i < res.n; i++) {
+        const sift_keypoint &k = res.keypoints[i];
+        keypoints.emplace_back(k.x, k.y, k.size, k.angle, k.response, k.octave, k.class_id);
+        descriptors.emplace_back(res.descriptors + (size_t)i * 128, res.descriptors + (size_t)(i + 1) * 128);
     }
-    {
-        // the reference's five TIMEIT stages (sift.cpp:71,72,86,87,92); the DoG
-        // subtraction is fused into the blur launches, so its own time is zero
-        const double blur = t.ms[SIFT_STAGE_BLUR_L1] + t.ms[SIFT_STAGE_BLUR_L2] + t.ms[SIFT_STAGE_BLUR_L3] +
-                            t.ms[SIFT_STAGE_BLUR_L4] + t.ms[SIFT_STAGE_BLUR_L5];
-        const double extrema = t.ms[SIFT_STAGE_GRADIENT] + t.ms[SIFT_STAGE_EXTREMA] + t.ms[SIFT_STAGE_LOCALIZE];
-        std::cerr << "elapsed time: gen_gaussian_images: " << 1e-3 * blur << "s\n";
-        std::cerr << "elapsed time: gen_dog_images: " << 0.0 << "s\n";
-        std::cerr << "elapsed time: gen_scale_space_extrema: " << 1e-3 * extrema << "s\n";
-        std::cerr << "elapsed time: clean_keypoints: " << 1e-3 * t.ms[SIFT_STAGE_CLEAN] << "s\n";
-        std::cerr << "elapsed time: get_descriptors: " << 1e-3 * t.ms[SIFT_STAGE_DESCRIPTOR] << "s\n";
-
-        const int n = counts.keypoints;
-        std::vector<sift_keypoint> kps((size_t)n);
-        std::vector<double> desc((size_t)n * 128);
-        int32_t got = 0;
-        check(sift_batch_download(batch, 0, n, kps.data(), nullptr, desc.data(), &got), "sift_batch_download");
-        keypoints.clear();
-        descriptors.clear();
-        for (int i = 0; i < n; i++) {
-            keypoints.emplace_back(kps[i].x, kps[i].y, kps[i].size, kps[i].angle, kps[i].response, kps[i].octave,
-                                   kps[i].class_id);
-            descriptors.emplace_back(desc.begin() + (size_t)i * 128, desc.begin() + (size_t)(i + 1) * 128);
-        }
-        base = cv::Mat(2 * height_, 2 * width_, CV_64FC1);  // sift.cpp:45
-        check(sift_batch_get_level(batch, 0, 0, 0, SIFT_LEVEL_GAUSS, base.ptr<double>(0)), "sift_batch_get_level");
-    }
+    sift_result_free(&res);
     std::cerr << "Keypoints Calculated: " << keypoints.size() << "\n";
     dump_keypoints();
     std::cerr << "Completed SIFT for " << name << "\n\n";
@@ -148,10 +114,26 @@ cv::Mat sift_handler::get() const {
 
 // sift.cpp:114-121
 void sift_handler::dump_keypoints() {
+    // Same bytes as the reference's `fout << x << "," << y << "," << size << "," << angle << std::endl`: a float goes
+    // through the stream as "%g" with six significant digits, which is what to_chars(general, 6) produces; the lines
+    // are assembled in memory and written once.
+    std::string text;
+    text.reserve(this->keypoints.size() * 48);
+    char buf[32];
+    auto put = [&](float v, char sep) {
+        const auto r = std::to_chars(buf, buf + sizeof(buf), (double)v, std::chars_format::general, 6);
+        text.append(buf, r.ptr);
+        text.push_back(sep);
+    };
+    for (auto &kpt : this->keypoints) {
+        put(kpt.pt.x, ',');
+        put(kpt.pt.y, ',');
+        put(kpt.size, ',');
+        put(kpt.angle, '\n');
+    }
     std::ofstream fout;
-    fout.open(this->name + ".csv", std::ios::out);
-    // same bytes as the reference's per-line std::endl, written with one flush at the end
-    for (auto &kpt : this->keypoints) fout << kpt.pt.x << "," << kpt.pt.y << "," << kpt.size << "," << kpt.angle << "\n";
+    fout.open(this->name + ".csv", std::ios::out | std::ios::binary);
+    fout.write(text.data(), (std::streamsize)text.size());
     fout.close();
 }
 

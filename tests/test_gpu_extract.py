@@ -290,3 +290,35 @@ def test_repeated_small_runs_are_identical(sift_lib, ctx):
                 assert np.array_equal(kp, want[0][0]) and np.array_equal(desc.astype(np.float64), want[0][1]), (it, i)
     finally:
         b.close()
+
+
+@pytest.mark.gpu
+def test_base_image_is_the_constructors_base(ctx, oracle, golden):
+    """sift_base_image_gray8 = resize x2 + GaussianBlur of the constructor (sift.cpp:40-45), bit for bit."""
+    gray = golden("leaves_320x240_seed7")["gray"]
+    o = oracle.OracleSift(gray).exec(threads=4)
+    base = ctx.base_image(gray)
+    assert base.shape == (480, 640) and np.array_equal(base, o.gauss(0, 0))
+    kp, desc, _ = ctx.extract(gray)                 # the workspace it shares with extract() is left usable
+    g = golden("leaves_320x240_seed7")
+    check_keypoints(kp, desc, g["keypoints"], g["descriptors"])
+
+
+@pytest.mark.gpu
+def test_stage_timed_call_returns_the_same_result_and_five_times(ctx, golden):
+    g = golden("lenna")
+    kp, desc, _ = ctx.extract(g["gray"])
+    kp2, desc2, ms = ctx.extract_stages(g["gray"])
+    assert np.array_equal(kp, kp2) and np.array_equal(desc, desc2)
+    assert len(ms) == 5 and ms[1] == 0.0 and all(m >= 0 for m in ms) and 0.05 < sum(ms) < 100
+    assert ms[0] > 0 and ms[2] > 0 and ms[4] > 0
+
+
+@pytest.mark.gpu
+def test_2048x1080_frame_standing_in_for_2k_png(sift_lib, ctx, oracle):
+    """BASELINE config 2 names res/2k.png, which the reference checkout does not contain; one dead-leaves frame of
+    2048 x 1080 (seed 2) stands in for it: full pipeline against the oracle."""
+    img = sift_lib.synth_dead_leaves(2, 0, 2048, 1080)
+    kp, desc, o = run_both(sift_lib, ctx, oracle, img, check_pyramid=False)
+    assert len(kp) > 3000
+    assert np.array_equal(desc, o.descriptors().astype(desc.dtype))
