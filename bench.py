@@ -3,19 +3,22 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = exec() (pyramid + DoG, extrema, clean, descriptors) over one batch
-of synthetic 1920x1080 frames per GPU, frames already resident in HBM.  Frames
-are distinct `dead-leaves` images (seed 1, frame index = global frame number),
-sharded over ranks by frame index with no data-path collective ("weak"
-scaling: every rank runs the same number of frames per step).
+One "step" = exec() (pyramid, extrema + gradient planes, localisation and
+orientation, clean, descriptors) over one batch of synthetic 1920x1080 frames
+per GPU, frames already resident in HBM.  Frames are distinct `dead-leaves`
+images (seed 1, frame index = global frame number), sharded over ranks by frame
+index with no data-path collective ("weak" scaling: every rank runs the same
+number of frames per step).
 
-Rank 0 prints ONE JSON line: whole-job frames/s, the HBM roofline of the
+Rank 0 prints ONE JSON line: whole-job frames/s; the HBM roofline of the
 dominant pyramid kernel measured with HIP events on the engine's own stream,
-per-stage device time shares, the matcher's pairs/s and MFMA fraction, and the
-CPU oracle timed on a bounded sample of the same workload.
+and a bound + fraction for every other heavy kernel; per-stage device times;
+host-frames-in / host-results-out throughput; the matcher on the per-GPU share
+of the 1 M x 10 M configuration (search + merge + ratio test) with its MFMA
+fraction; and the CPU oracle timed on bounded samples of both workloads.
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -26,15 +29,28 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak
 MFMA_I8_PEAK_TFLOPS = 5000.0  # dense int8 MFMA peak = 2x the 2.5 PF bf16 dense peak
+# ds_add_f64 retires 64 lanes per 8 cycles per CU when no two lanes collide (scripts/ubench/lds_atomic.hip):
+# 256 CUs x 8 lanes/clk x 2.4 GHz
+LDS_F64_ATOMIC_PEAK_GOPS = 256 * 8 * 2.4
+
+
+def source_hash():
+    """Identity of the kernel sources: counter-derived figures in profiles/ are only quoted for the build they were
+    measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(HERE, "sift_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pyramid_geometry(w, h):
     import sift_amd as S
-    n = S.num_octaves(w, h)
-    dims = [S.octave_dims(w, h, o) for o in range(n)]
-    return dims
+    return [S.octave_dims(w, h, o) for o in range(S.num_octaves(w, h))]
 
 
 def main():
@@ -48,13 +64,16 @@ def main():
     ap.add_argument("--pool", type=int, default=2, help="distinct batches resident in HBM, cycled over steps")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams) per GPU; the batch is split evenly between them")
-    ap.add_argument("--knn-queries", type=int, default=262144)
-    ap.add_argument("--knn-train", type=int, default=1 << 20)
+    ap.add_argument("--knn-queries", type=int, default=1 << 20, help="queries (the 1 M of the 1 M x 10 M configuration)")
+    ap.add_argument("--knn-train", type=int, default=1310720, help="train rows per GPU (10 M / 8)")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--force-sharded-knn", action="store_true",
                     help="run the sharded-matcher leg even with one rank (exercises the RCCL exchange path)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-knn-seconds", type=float, default=10.0)
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-frames", type=int, default=128)
     args = ap.parse_args()
 
     import torch
@@ -136,7 +155,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "batch of synthetic %dx%d dead-leaves frames (seed 1), image-sharded, "
-                               "full exec(): pyramid+DoG, extrema, clean, descriptors" % (W, H),
+                               "full exec(): pyramid, extrema + gradients, localise + orient, clean, descriptors" % (W, H),
                    "frames_per_gpu_per_step": B, "streams_per_gpu": nstreams, "distinct_batches_in_hbm": npool,
                    "keypoints_per_frame_mean": kp_mean},
     }
@@ -188,62 +207,153 @@ def main():
             prof = batch.run_profiled(B)
         dims = pyramid_geometry(W, H)
         P = sum(w * h for w, h in dims)
+        P0 = dims[0][0] * dims[0][1]
+        P_scanned = sum(w * h for w, h in dims if w > 10 and h > 10)   # octaves with a non-empty scan range
         total_ms = sum(v["ms"] for v in prof.values())
         stages = {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
-                      "share": round(v["ms"] / total_ms, 4)} for k, v in prof.items()}
+                      "share": round(v["ms"] / total_ms, 4)} for k, v in prof.items() if v["launches"]}
         out["stages_per_batch"] = stages
-        # dominant pyramid kernel: the blur level with the largest device time.
-        # Algorithmic bytes of one blur level over all octaves: read G[j-1],
-        # write G[j], write D[j-1] = 3 * 8 B per pixel.
+
+        traffic = {}
+        tpath = os.path.join(HERE, "profiles", "traffic.json")
+        if os.path.exists(tpath) and (W, H) == (1920, 1080):
+            # measured with PMC counters on 1080p batches; only quoted for the kernel sources they were measured on
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("_source_hash") == source_hash():
+                    traffic = {k: v * B / tj["_frames_per_launch"] for k, v in tj.items()
+                               if not k.startswith("_") and not k.endswith("_detail")}
+            except Exception:
+                traffic = {}
+
+        # Dominant pyramid kernel: the blur level with the largest device time.  Algorithmic bytes of one blur level
+        # over all octaves, as the reference formulates the work (GaussianBlur, sift.cpp:150, then subtract,
+        # sift.cpp:173): read G[j-1], write G[j], write D[j-1] = 3 x 8 B per pixel.  This engine never stores D (its
+        # two readers subtract in registers), so the bytes it has to MOVE are 2 x 8 B per pixel; that figure is
+        # reported beside the algorithmic one as `moved`.
         blur = {k: v for k, v in prof.items() if k.startswith("blur_l")}
         dom = max(blur, key=lambda k: blur[k]["ms"])
         lv = blur[dom]
         bytes_per_launch = 3 * 8 * P * B / lv["launches"]
+        moved_per_launch = 2 * 8 * P * B / lv["launches"]
         avg_ms = lv["ms"] / lv["launches"]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        moved = moved_per_launch / (avg_ms * 1e-3) / 1e9
         taps = {"blur_l1": 11, "blur_l2": 13, "blur_l3": 17, "blur_l4": 21, "blur_l5": 27}[dom]
-        traffic = None
-        tpath = os.path.join(HERE, "profiles", "traffic.json")
-        if os.path.exists(tpath) and (W, H) == (1920, 1080):
-            # measured with PMC counters on 1080p batches; bytes per launch scale with the frames per launch
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj[dom] * B / tj["_frames_per_launch"]
-            except Exception:
-                traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "k_blur_march<%d> (%d taps)" % (taps // 2, taps),
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": traffic[dom] / lv["launches"] if dom in traffic else None,
                            "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "launches_per_batch": lv["launches"]}
+                           "launches_per_batch": lv["launches"],
+                           "moved": {"bytes_per_launch": moved_per_launch, "achieved": moved, "frac": moved / HBM_PEAK_GBS,
+                                     "note": "bytes this kernel has to move: the difference-of-Gaussians level is not stored"}}
         pyr_ms = prof["base"]["ms"] + sum(v["ms"] for v in blur.values())
-        pyr_bytes = (W * H + 8 * dims[0][0] * dims[0][1] + 15 * 8 * P) * B
+        pyr_bytes = (W * H + 8 * P0 + 15 * 8 * P) * B
+        pyr_moved = (W * H + 8 * P0 + 10 * 8 * P) * B
         out["pyramid"] = {"ms_per_batch": pyr_ms, "algorithmic_GBs": pyr_bytes / (pyr_ms * 1e-3) / 1e9,
-                          "frac_of_hbm_peak": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                          "frac_of_hbm_peak": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "moved_GBs": pyr_moved / (pyr_ms * 1e-3) / 1e9,
+                          "moved_frac_of_hbm_peak": pyr_moved / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "per_level_moved_frac": {k: round(2 * 8 * P * B / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                   for k, v in sorted(blur.items())}}
 
-        # ---- matcher: pairs/s and MFMA fraction --------------------------------
+        # every other heavy kernel: what bounds it and how close it runs to that bound
+        kernels = {}
+        ex = prof["extrema"]
+        ex_bytes = (6 * 8 + 3 * 16) * P_scanned * B      # six Gaussian levels read, three gradient planes written
+        kernels["extrema_gradients"] = {
+            "kernel": "k_extrema_grad", "bound": "hbm", "ms_per_batch": ex["ms"],
+            "algorithmic_bytes_per_batch": ex_bytes, "achieved": ex_bytes / (ex["ms"] * 1e-3) / 1e9, "unit": "GB/s",
+            "peak": HBM_PEAK_GBS, "frac": ex_bytes / (ex["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic.get("k_extrema_grad")}
+        work = batch.descriptor_work(B)
+        dsc = prof["descriptor"]
+        upd = float(work[:, 1].sum())
+        kernels["descriptor"] = {
+            "kernel": "k_descriptors", "bound": "lds-atomic", "ms_per_batch": dsc["ms"],
+            "window_samples_per_batch": float(work[:, 0].sum()), "histogram_updates_per_batch": upd,
+            "achieved": upd / (dsc["ms"] * 1e-3) / 1e9, "unit": "G ds_add_f64 lanes/s",
+            "peak": LDS_F64_ATOMIC_PEAK_GOPS, "frac": upd / (dsc["ms"] * 1e-3) / 1e9 / LDS_F64_ATOMIC_PEAK_GOPS,
+            "note": "LDS busy 80 % of the kernel's cycles by counters (profiles/); peak = conflict-free ds_add_f64 rate",
+            "traffic": traffic.get("k_descriptors")}
+        base = prof["base"]
+        base_bytes = (W * H + 8 * P0) * B
+        kernels["base"] = {"kernel": "k_base_march<5>", "bound": "hbm (write-only stream)", "ms_per_batch": base["ms"],
+                           "achieved": base_bytes / (base["ms"] * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                           "frac": base_bytes / (base["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get("base")}
+        out["kernels"] = kernels
+
+        # ---- host frames in -> host keypoints + descriptors out ------------------
+        if not args.no_e2e:
+            batch.close()
+            batch = None
+            g = S.Group([ctx])
+            nf = min(args.e2e_frames, host.shape[0])
+            g.extract_batch_raw(host[:min(32, nf)], 16)         # workspaces, page-locked buffers
+            t1 = time.perf_counter()
+            total_kp = g.extract_batch_raw(host[:nf], 16)
+            dt = time.perf_counter() - t1
+            out["end_to_end"] = {"frames": nf, "frames_per_s": nf / dt, "ms_per_frame": 1e3 * dt / nf,
+                                 "keypoints": total_kp,
+                                 "what": "sift_extract_batch_u8: pageable host frames in, host keypoints + 128-byte "
+                                         "descriptors out, 16 frames per launch, uploads and downloads through "
+                                         "page-locked staging overlapped with the kernels of the neighbouring chunks"}
+            g.close()
+
+        # ---- matcher: pairs/s and MFMA fraction on the per-GPU share of 1 M x 10 M ------
         if not args.no_knn:
             nq, nt = args.knn_queries, args.knn_train
             tr = S.synth_descriptors(5, nt)
             qq = S.synth_queries(6, tr, nq)
             d_t = torch.from_numpy(tr).cuda()
             d_q = torch.from_numpy(qq).cuda()
+            d_p = torch.empty((nq, 4), dtype=torch.int32, device="cuda")
             d_o = torch.empty((nq, 4), dtype=torch.int32, device="cuda")
+            d_a = torch.empty((nq,), dtype=torch.uint8, device="cuda")
             torch.cuda.synchronize()
-            ctx.knn2_device(d_q.data_ptr(), nq, d_t.data_ptr(), nt, 0, d_o.data_ptr())
+
+            def match():
+                ctx.knn2_device(d_q.data_ptr(), nq, d_t.data_ptr(), nt, 0, d_p.data_ptr())
+                ctx.knn2_merge_device(d_p.data_ptr(), 1, nq, d_o.data_ptr(), d_a.data_ptr())   # ratio test
+
+            match()
             ctx.synchronize()
             reps = 3
             t1 = time.perf_counter()
             for _ in range(reps):
-                ctx.knn2_device(d_q.data_ptr(), nq, d_t.data_ptr(), nt, 0, d_o.data_ptr())
+                match()
             ctx.synchronize()
             dt = (time.perf_counter() - t1) / reps
             pairs = nq * nt / dt
             tflops = 2 * 128 * nq * nt / dt / 1e12
             out["knn"] = {"queries": nq, "train": nt, "ms": dt * 1e3, "pairs_per_s": pairs,
+                          "accepted": int(d_a.sum().item()),
+                          "what": "sift_knn2_device + sift_knn2_merge_device with the ratio test, operands in HBM; "
+                                  "one GPU's share of 1 M queries x 10 M train rows sharded 8 ways",
                           "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_I8_PEAK_TFLOPS,
                                        "unit": "TOP/s (int8)", "frac": tflops / MFMA_I8_PEAK_TFLOPS}}
-            del d_t, d_q, d_o
+            if not args.no_cpu and world == 1:
+                from oracle import oracle as O
+                cores = min(16, os.cpu_count() or 1)
+                # bounded sample: as many of the same queries against the same train rows as fit the time budget
+                probe = 16
+                t1 = time.perf_counter()
+                O.knn2_u8(qq[:probe], tr, threads=cores)
+                rate = probe * nt / (time.perf_counter() - t1)
+                n_s = int(max(probe, min(nq, args.cpu_knn_seconds * rate / nt)))
+                t1 = time.perf_counter()
+                ci1, cd1, ci2, cd2, cacc = O.knn2_u8(qq[:n_s], tr, threads=cores)
+                dtc = time.perf_counter() - t1
+                got = d_o[:n_s].cpu().numpy()
+                same = bool(np.array_equal(got[:, 0], cd1) and np.array_equal(got[:, 1], ci1) and
+                            np.array_equal(got[:, 2], cd2) and np.array_equal(got[:, 3], ci2) and
+                            np.array_equal(d_a[:n_s].cpu().numpy(), cacc))
+                out["knn"]["cpu_baseline"] = {"value": n_s * nt / dtc, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                              "sample": "the first %d of the same queries against all %d train rows "
+                                                        "through the CPU oracle's exact brute force" % (n_s, nt),
+                                              "gpu_results_identical_on_sample": same}
+            del d_t, d_q, d_p, d_o, d_a
 
         # ---- CPU oracle on a bounded sample of the same workload ----------------
         if not args.no_cpu and world == 1:  # the CPU baseline is reported at N = 1 only

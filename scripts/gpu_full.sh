@@ -18,6 +18,7 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fet
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o x -- python3 scripts/prof_extract.py 64 > $O/pmc_write.log 2>&1 || { tail -20 $O/pmc_write.log; exit 1; }
 timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_cal_fetch -o x -- scripts/ubench/copy8 1024 > $O/pmc_cal_fetch.log 2>&1 || { tail -20 $O/pmc_cal_fetch.log; exit 1; }
 timeout -s KILL 60 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_cal_write -o x -- scripts/ubench/copy8 1024 > $O/pmc_cal_write.log 2>&1 || { tail -20 $O/pmc_cal_write.log; exit 1; }
+bash scripts/gpu_desc_pmc.sh final > $O/desc_pmc_run.log 2>&1 || { tail -20 $O/desc_pmc_run.log; exit 1; }
 for d in pmc_fetch pmc_write pmc_cal_fetch pmc_cal_write; do echo "== $d"; python scripts/pmc_summary.py $O/$d; done > $O/pmc_all.txt
 python scripts/make_traffic.py $O 64 > $O/traffic_summary.txt && cp profiles/traffic.json $O/traffic.json
 tail -12 $O/traffic_summary.txt

@@ -9,8 +9,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import source_hash  # noqa: E402  (identity of the kernel sources the counters were measured on)
 
 out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -38,10 +42,11 @@ fetch_factor = known_kib / (cal_f["k_copy8"] / ncf["k_copy8"])
 write_factor = known_kib / (cal_w["k_copy8"] / ncw["k_copy8"])
 res = {"_calibration": {"fetch_factor": fetch_factor, "write_factor": write_factor,
                         "note": "known bytes / reported bytes of an 8-byte-per-lane streaming copy of 1 GiB"},
-       "_frames_per_launch": frames,
+       "_frames_per_launch": frames, "_source_hash": source_hash(),
        "_unit": "HBM bytes per launch (mean over the launches of two %d-frame 1080p batches)" % frames}
 names = {"k_blur_march<5>": "blur_l1", "k_blur_march<6>": "blur_l2", "k_blur_march<8>": "blur_l3",
-         "k_blur_march<10>": "blur_l4", "k_blur_march<13>": "blur_l5", "k_base_march<5>": "base"}
+         "k_blur_march<10>": "blur_l4", "k_blur_march<13>": "blur_l5", "k_base_march<5>": "base",
+         "k_descriptors<false>": "k_descriptors"}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):
         continue
