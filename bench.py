@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--cpu-knn-seconds", type=float, default=10.0)
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-frames", type=int, default=128)
+    ap.add_argument("--e2e-frames", type=int, default=256)
     args = ap.parse_args()
 
     import torch
@@ -243,7 +243,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "k_blur_march<%d> (%d taps)" % (taps // 2, taps),
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic[dom] / lv["launches"] if dom in traffic else None,
+                           "traffic": traffic.get(dom),   # mean HBM bytes per launch, like the algorithmic figure
                            "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                            "launches_per_batch": lv["launches"],
                            "moved": {"bytes_per_launch": moved_per_launch, "achieved": moved, "frac": moved / HBM_PEAK_GBS,
@@ -266,7 +266,7 @@ def main():
             "kernel": "k_extrema_grad", "bound": "hbm", "ms_per_batch": ex["ms"],
             "algorithmic_bytes_per_batch": ex_bytes, "achieved": ex_bytes / (ex["ms"] * 1e-3) / 1e9, "unit": "GB/s",
             "peak": HBM_PEAK_GBS, "frac": ex_bytes / (ex["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": traffic.get("k_extrema_grad")}
+            "traffic": traffic["k_extrema_grad"] * ex["launches"] if "k_extrema_grad" in traffic else None}
         work = batch.descriptor_work(B)
         dsc = prof["descriptor"]
         upd = float(work[:, 1].sum())
@@ -289,16 +289,19 @@ def main():
             batch.close()
             batch = None
             g = S.Group([ctx])
-            nf = min(args.e2e_frames, host.shape[0])
-            g.extract_batch_raw(host[:min(32, nf)], 16)         # workspaces, page-locked buffers
+            # the same frames per launch as the resident batches, so that every launch of the run has one shape
+            nf = max(B, args.e2e_frames // B * B)
+            e2e_host = np.concatenate([host] * ((nf + host.shape[0] - 1) // host.shape[0]))[:nf]
+            g.extract_batch_raw(e2e_host[:2 * B], B)         # workspaces, page-locked buffers
             t1 = time.perf_counter()
-            total_kp = g.extract_batch_raw(host[:nf], 16)
+            total_kp = g.extract_batch_raw(e2e_host, B)
             dt = time.perf_counter() - t1
             out["end_to_end"] = {"frames": nf, "frames_per_s": nf / dt, "ms_per_frame": 1e3 * dt / nf,
                                  "keypoints": total_kp,
                                  "what": "sift_extract_batch_u8: pageable host frames in, host keypoints + 128-byte "
-                                         "descriptors out, 16 frames per launch, uploads and downloads through "
-                                         "page-locked staging overlapped with the kernels of the neighbouring chunks"}
+                                         "descriptors out, %d frames per launch, uploads and downloads through "
+                                         "page-locked staging overlapped with the kernels of the neighbouring chunks" % B}
+            del e2e_host
             g.close()
 
         # ---- matcher: pairs/s and MFMA fraction on the per-GPU share of 1 M x 10 M ------
