@@ -144,6 +144,11 @@ int sift_batch_descriptor_work(sift_batch *b, int n_frames, int64_t *work);
 /* Parity/debug accessors (host copies of intermediate images and lists). */
 #define SIFT_LEVEL_GAUSS 0 /* gauss_images[oct][lvl], lvl 0..5 (sift.hpp:115) */
 #define SIFT_LEVEL_DOG 1   /* images[oct][lvl], lvl 0..4 (sift.hpp:114) */
+/* Per-pixel gradient of gauss_images[oct][lvl], lvl 1..3, as the orientation and descriptor windows evaluate it per
+ * sample (sift.cpp:410-415, :507-510): magnitude sqrt(dx^2 + dy^2) and direction atan2(dy, dx)*180/pi with
+ * dx = L(y,x+1) - L(y,x-1), dy = L(y-1,x) - L(y+1,x); zero on the one-pixel image border, which no window samples. */
+#define SIFT_LEVEL_GRAD_MAG 2
+#define SIFT_LEVEL_GRAD_DIR 3
 int sift_batch_get_level(sift_batch *b, int frame, int oct, int lvl, int kind, double *out);
 /* Candidates as (oct, img, i, j) int32 quadruples in unspecified order. */
 int sift_batch_get_candidates(sift_batch *b, int frame, int capacity, int32_t *quads, int32_t *n);

@@ -20,6 +20,8 @@ SIFT_ERR_NOT_INTEGRAL = -4
 
 LEVEL_GAUSS = 0
 LEVEL_DOG = 1
+LEVEL_GRAD_MAG = 2
+LEVEL_GRAD_DIR = 3
 
 STAGE_NAMES = ("base", "blur_l1", "blur_l2", "blur_l3", "blur_l4", "blur_l5", "extrema", "localize_orient", "clean",
                "descriptor", "gradient")

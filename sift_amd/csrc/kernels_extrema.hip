@@ -400,6 +400,7 @@ constexpr int OCOPIES = 16;
 constexpr int OSTRIDE = OCOPIES + 1;  // bins start one LDS bank pair apart
 constexpr int OWAVES = 4;             // waves (= keypoints in flight) per workgroup
 constexpr int WTAB = 128;
+constexpr int OSAMP = 4;             // samples per lane per trip of the window loop (2 and 8 measure the same)
 
 __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeypoint *__restrict__ localized,
                                                          int kp_cap, DevKeypoint *__restrict__ oriented,
@@ -444,12 +445,12 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
         // Four samples per lane per trip.  Gradient loads are unconditional (addresses clamped
         // into the plane) and the weight-table reads come before the first atomic, so all of a
         // trip's reads are in flight together; samples outside the image are discarded.
-        for (int s0 = lane; s0 < total; s0 += 64 * 4) {
-            Grad g[4];
-            double wgt[4];
-            bool ok[4];
+        for (int s0 = lane; s0 < total; s0 += 64 * OSAMP) {
+            Grad g[OSAMP];
+            double wgt[OSAMP];
+            bool ok[OSAMP];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < OSAMP; u++) {
                 const int ii = qi - radius, jj = rj - radius;
                 const int y = base_y + ii, x = base_x + jj;
                 ok[u] = s0 + 64 * u < total && y > 0 && y < h - 1 && x > 0 && x < w - 1;  // sift.cpp:407,409
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < OSAMP; u++) {
                 if (!ok[u]) continue;
                 // ((int)round(ori*36/360) % 36 + 36) % 36 (sift.cpp:416); |ori| <= 180, so the rounded value lies in [-18, 18]
                 const int k = round_half_away(div_360(g[u].ori * BINS));

@@ -202,18 +202,38 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
         {   // row pass: lane <-> row, 8 consecutive outputs per thread
             const int row = tid & (MCH - 1), cx = tid / MCH;
             const double *p = s_in + row * G::PIN + cx * CX;
-            double v[CX + 2 * R];
-#pragma unroll
-            for (int k = 0; k < CX + 2 * R; k++) v[k] = p[k];
             double *q = ring + ((MCH * s + row) % G::RING) * G::PR + cx * CX;
-            // independent accumulation chains, advanced one tap at a time
+            // The window of CX + 2R inputs is streamed through registers ECH elements at a time, the next chunk's
+            // LDS reads issued before the current chunk is consumed; an element k adds its term c[k-m]*v[k] to
+            // every output m it belongs to, so each output still accumulates its taps left to right.  The
+            // scheduling barriers keep the compiler from hoisting every read to the top (which costs 2(CX+2R)
+            // registers and a third of the waves).
+            constexpr int NEL = CX + 2 * R, ECH = 8, NCH = (NEL + ECH - 1) / ECH;
             double acc[CX];
+            double buf[2][ECH];
 #pragma unroll
-            for (int m = 0; m < CX; m++) acc[m] = taps.c[0] * v[m];
+            for (int u = 0; u < ECH; u++) buf[0][u] = p[u];
 #pragma unroll
-            for (int t = 1; t <= 2 * R; t++) {
+            for (int c = 0; c < NCH; c++) {
+                if (c + 1 < NCH) {
 #pragma unroll
-                for (int m = 0; m < CX; m++) acc[m] += taps.c[t] * v[m + t];
+                    for (int u = 0; u < ECH; u++)
+                        if ((c + 1) * ECH + u < NEL) buf[(c + 1) & 1][u] = p[(c + 1) * ECH + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < ECH; u++) {
+                    const int k = c * ECH + u;
+                    if (k >= NEL) break;
+                    const double vk = buf[c & 1][u];
+#pragma unroll
+                    for (int m = 0; m < CX; m++) {
+                        const int t = k - m;
+                        if (t == 0) acc[m] = taps.c[0] * vk;
+                        else if (t > 0 && t <= 2 * R) acc[m] += taps.c[t] * vk;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int m = 0; m < CX; m++) q[m] = acc[m];
@@ -227,20 +247,71 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
             const int y0 = ys - R + rel0;  // image row of the first output row
             const int gx = tx0 + x;
             if (y0 + CY > ys && y0 < ye && gx < w) {
-                double v[CY + 2 * R];
-                int slot = (rel0 - R + 8 * G::RING) % G::RING;
+                // Ring row of window element k (0 .. CY+2R-1); the base slot is a scalar.
+                const int slot0 = (rel0 - R + 8 * G::RING) % G::RING;
+                auto ld = [&](int k) {
+                    int sl = slot0 + k;
+                    sl = sl >= G::RING ? sl - G::RING : sl;
+                    return ring[sl * G::PR + x];
+                };
+                // Output m is c[R]*v[m+R] plus, for t = 1..R in this order, c[R+t]*(v[m+R+t] + v[m+R-t]).  The
+                // upper and lower operands of the CY outputs at step t are two windows of CY elements that slide
+                // outwards by one element per step, so the column is streamed through registers too: TCH steps'
+                // worth of new elements are read one chunk ahead of their use.
+                constexpr int TCH = 4, NTC = (R + TCH - 1) / TCH;
+                double acc[CY], hi_w[CY], lo_w[CY];
+                {
+                    double cen[CY];
 #pragma unroll
-                for (int k = 0; k < CY + 2 * R; k++) {
-                    v[k] = ring[slot * G::PR + x];
-                    slot = slot + 1 == G::RING ? 0 : slot + 1;
+                    for (int m = 0; m < CY; m++) cen[m] = ld(R + m);
+#pragma unroll
+                    for (int m = 0; m < CY; m++) acc[m] = taps.c[R] * cen[m];
+#pragma unroll
+                    for (int m = 0; m + 1 < CY; m++) hi_w[m] = cen[m + 1];
+                    hi_w[CY - 1] = ld(R + CY);
+#pragma unroll
+                    for (int m = 1; m < CY; m++) lo_w[m] = cen[m - 1];
+                    lo_w[0] = ld(R - 1);
                 }
-                double acc[CY];
+                double fresh_hi[2][TCH], fresh_lo[2][TCH];
+                // after step t the windows need v[R+t+CY] and v[R-t-1] (nothing after the last step)
 #pragma unroll
-                for (int m = 0; m < CY; m++) acc[m] = taps.c[R] * v[m + R];
+                for (int u = 0; u < TCH; u++) {
+                    const int t = 1 + u;
+                    if (t < R) {
+                        fresh_hi[0][u] = ld(R + t + CY);
+                        fresh_lo[0][u] = ld(R - t - 1);
+                    }
+                }
 #pragma unroll
-                for (int t = 1; t <= R; t++) {
+                for (int c = 0; c < NTC; c++) {
+                    if (c + 1 < NTC) {
 #pragma unroll
-                    for (int m = 0; m < CY; m++) acc[m] += taps.c[R + t] * (v[m + R + t] + v[m + R - t]);
+                        for (int u = 0; u < TCH; u++) {
+                            const int t = 1 + (c + 1) * TCH + u;
+                            if (t < R) {
+                                fresh_hi[(c + 1) & 1][u] = ld(R + t + CY);
+                                fresh_lo[(c + 1) & 1][u] = ld(R - t - 1);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < TCH; u++) {
+                        const int t = 1 + c * TCH + u;
+                        if (t > R) break;
+#pragma unroll
+                        for (int m = 0; m < CY; m++) acc[m] += taps.c[R + t] * (hi_w[m] + lo_w[m]);
+                        if (t < R) {
+#pragma unroll
+                            for (int m = 0; m + 1 < CY; m++) hi_w[m] = hi_w[m + 1];
+                            hi_w[CY - 1] = fresh_hi[c & 1][u];
+#pragma unroll
+                            for (int m = CY - 1; m > 0; m--) lo_w[m] = lo_w[m - 1];
+                            lo_w[0] = fresh_lo[c & 1][u];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int m = 0; m < CY; m++) {

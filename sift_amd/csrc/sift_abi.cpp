@@ -581,6 +581,21 @@ int sift_batch_get_level(sift_batch *b, int frame, int oct, int lvl, int kind, d
     if (!b || !out) return fail(SIFT_ERR_INVALID, "NULL argument");
     if (frame < 0 || frame >= b->max_frames || oct < 0 || oct >= b->pyr.octaves)
         return fail(SIFT_ERR_INVALID, "frame or octave out of range");
+    if (kind == SIFT_LEVEL_GRAD_MAG || kind == SIFT_LEVEL_GRAD_DIR) {
+        if (lvl < 1 || lvl > SCALES) return fail(SIFT_ERR_INVALID, "gradient planes exist for levels 1..3");
+        if (!b->pyr.grad[oct]) return fail(SIFT_ERR_INVALID, "this octave is too small to be scanned: it has no gradient planes");
+        HIP_TRY(hipSetDevice(b->ctx->device));
+        const size_t px = (size_t)b->pyr.w[oct] * b->pyr.h[oct];
+        void *stage = nullptr;
+        int rc = stage_in(b->ctx, px * sizeof(Grad), &stage);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(stage, b->pyr.grad[oct] + grad_off(b->pyr, oct, frame, lvl), px * sizeof(Grad), hipMemcpyDeviceToHost,
+                               b->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        const Grad *g = static_cast<const Grad *>(stage);
+        for (size_t i = 0; i < px; i++) out[i] = kind == SIFT_LEVEL_GRAD_MAG ? g[i].mag : g[i].ori;
+        return SIFT_OK;
+    }
     const int nl = kind == SIFT_LEVEL_GAUSS ? IMAGES : NDOG;
     if ((kind != SIFT_LEVEL_GAUSS && kind != SIFT_LEVEL_DOG) || lvl < 0 || lvl >= nl)
         return fail(SIFT_ERR_INVALID, "level out of range");

@@ -322,3 +322,68 @@ def test_2048x1080_frame_standing_in_for_2k_png(sift_lib, ctx, oracle):
     kp, desc, o = run_both(sift_lib, ctx, oracle, img, check_pyramid=False)
     assert len(kp) > 3000
     assert np.array_equal(desc, o.descriptors().astype(desc.dtype))
+
+
+def _numpy_gradients(L):
+    """sift.cpp:410-415 per pixel in doubles, with the C library's atan2 (math.atan2), which is what the reference
+    and the oracle call; numpy's own vectorised arctan2 is a few ulps less accurate and decides exact-diagonal
+    gradients differently."""
+    import math
+    dx = np.zeros_like(L)
+    dy = np.zeros_like(L)
+    dx[1:-1, 1:-1] = L[1:-1, 2:] - L[1:-1, :-2]
+    dy[1:-1, 1:-1] = L[:-2, 1:-1] - L[2:, 1:-1]
+    mag = np.sqrt(dx * dx + dy * dy)
+    ang = (np.frompyfunc(math.atan2, 2, 1)(dy, dx).astype(np.float64) * 180) / np.pi
+    inner = np.zeros(L.shape, bool)
+    inner[1:-1, 1:-1] = True
+    return np.where(inner, mag, 0.0), np.where(inner, ang, 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["leaves", "diagonal_symmetry", "lenna", "tiny_and_huge"])
+def test_gradient_planes_against_libm(sift_lib, ctx, golden, kind):
+    """The device evaluates atan2 with its own table-and-series routine (hardware reciprocal seeds) and refines
+    results that land next to one of the 36 histogram bin boundaries; host libm is the reference's arithmetic.
+    Gradient magnitudes must be bit-identical, directions within 4 ulps of the degree value (two ulps of the
+    arctangent in radians, carried through the *180/pi conversion), and the orientation-histogram bin
+    round(direction*36/360) (sift.cpp:416) identical for every pixel of every plane."""
+    if kind == "leaves":
+        img = sift_lib.synth_dead_leaves(9, 0, 333, 205)
+    elif kind == "diagonal_symmetry":           # img == img.T: gradients exactly on the 45-degree directions
+        a = sift_lib.synth_dead_leaves(10, 0, 200, 200).astype(np.int32)
+        img = ((a + a.T) // 2).astype(np.uint8)
+    elif kind == "lenna":
+        img = golden("lenna")["gray"]
+    else:                                        # flat areas with single-level steps and full-range edges
+        yy, xx = np.mgrid[0:160, 0:224]
+        img = np.where((xx // 16 + yy // 16) % 2 == 0, 100, 101).astype(np.uint8)
+        img[40:120, 60:180] = np.where((xx[40:120, 60:180] * 3 + yy[40:120, 60:180]) % 7 < 3, 0, 255)
+    h, w = img.shape
+    b = ctx.batch(w, h, 1)
+    try:
+        b.upload(0, img)
+        b.run(1)
+        b.counts(1)
+        checked = 0
+        for oc in range(b.octaves):
+            ow, oh = sift_lib.octave_dims(w, h, oc)
+            if ow <= 10 or oh <= 10:
+                with pytest.raises(sift_lib.SiftError):
+                    b.level(0, oc, 1, sift_lib.LEVEL_GRAD_MAG)
+                continue
+            for lvl in (1, 2, 3):
+                L = b.level(0, oc, lvl, sift_lib.LEVEL_GAUSS)
+                mag, ang = _numpy_gradients(L)
+                gm = b.level(0, oc, lvl, sift_lib.LEVEL_GRAD_MAG)
+                gd = b.level(0, oc, lvl, sift_lib.LEVEL_GRAD_DIR)
+                assert np.array_equal(gm, mag), (oc, lvl)
+                err = np.abs(gd - ang)
+                assert (err <= 4 * np.spacing(np.maximum(np.abs(ang), 1e-300))).all(), (oc, lvl, err.max())
+                bins = lambda a: np.sign(a * 36 / 360) * np.floor(np.abs(a * 36 / 360) + 0.5)   # std::round
+                bad = np.argwhere(bins(gd) != bins(ang))
+                assert len(bad) == 0, (oc, lvl, len(bad), [(int(y), int(x), float(gd[y, x]).hex(), float(ang[y, x]).hex()) for y, x in bad[:4]])
+                checked += gm.size
+        assert checked > 10000
+    finally:
+        b.close()
