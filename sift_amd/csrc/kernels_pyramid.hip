@@ -49,7 +49,6 @@ struct MarchGeom {
     static constexpr int PIN = COLS | 1;   // odd pitch: lane<->row reads are conflict-free
     static constexpr int RING = MCH + 2 * R;
     static constexpr int PR = TW + 1;      // odd pitch: lane<->row writes are conflict-free
-    static constexpr int NLOAD = (MCH * COLS + NTHREADS - 1) / NTHREADS;
     static constexpr size_t LDS_BYTES = ((size_t)MCH * PIN + (size_t)RING * PR) * sizeof(double);
 };
 
@@ -126,51 +125,58 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
     const int ye = min(h, ys + strip_h);
     const int nsteps = (ye - ys + 2 * R + MCH - 1) / MCH;
 
-    // This thread's share of a MCH x COLS staging tile: fixed (row, column) per slot.  `fetch`
-    // issues the loads of step s into registers, `stage` writes them to the step's LDS buffer.
+    // This thread's share of a MCH x COLS staging tile.  `fetch` issues the loads of step s into registers,
+    // `stage` writes them to the LDS staging tile.
     constexpr bool kQuads = Source::kQuads;
     constexpr int QC = G::COLS / 2, NQUAD = (MCH / 2) * QC;
-    constexpr int NSLOT = kQuads ? (NQUAD + NTHREADS - 1) / NTHREADS : G::NLOAD;
+    // Blur levels: a thread owns one row of the tile and every TPR-th column of it, so that a step's loads and LDS
+    // writes are one base address plus compile-time offsets (no per-slot index registers live across the loop).
+    constexpr int TPR = NTHREADS / MCH, NS = (G::COLS + TPR - 1) / TPR;
+    constexpr int NSLOT = kQuads ? (NQUAD + NTHREADS - 1) / NTHREADS : NS;
     static_assert(!kQuads || ((R & 1) && !(MCH & 1) && !(TW & 1)), "quads need an odd tile origin and even tile sides");
-    int pf_row[NSLOT], pf_gx[NSLOT], pf_lds[NSLOT];
+    const int srow = tid / TPR, sc0 = tid % TPR;
+    const bool edge_x = tx0 - R < 0 || tx0 + TW + R > w;  // uniform over the workgroup: columns need reflecting
+    int pf_row[kQuads ? NSLOT : 1], pf_gx[kQuads ? NSLOT : 1], pf_lds[kQuads ? NSLOT : 1];
     double pf[kQuads ? 1 : NSLOT];
     int raw[kQuads ? NSLOT : 1][4];
+    if constexpr (kQuads) {
 #pragma unroll
-    for (int u = 0; u < NSLOT; u++) {
-        const int idx = tid + NTHREADS * u;
-        if constexpr (kQuads) {
+        for (int u = 0; u < NSLOT; u++) {
+            const int idx = tid + NTHREADS * u;
             const int r = 2 * (idx / QC), c = 2 * (idx % QC);
             pf_row[u] = idx < NQUAD ? r : -1;
             pf_gx[u] = tx0 - R + c;  // not reflected: border quads are recomputed
-            pf_lds[u] = r * G::PIN + c;
-        } else {
-            const int r = idx / G::COLS, c = idx % G::COLS;
-            pf_row[u] = idx < MCH * G::COLS ? r : -1;
-            pf_gx[u] = reflect101(tx0 - R + c, w);
             pf_lds[u] = r * G::PIN + c;
         }
     }
     auto fetch = [&](int s) {
         const int v0 = ys - R + MCH * s;
+        if constexpr (kQuads) {
 #pragma unroll
-        for (int u = 0; u < NSLOT; u++) {
-            if constexpr (kQuads) {
+            for (int u = 0; u < NSLOT; u++)
                 if ((u + 1) * NTHREADS <= NQUAD || pf_row[u] >= 0) source.load_quad(v0 + pf_row[u], pf_gx[u], raw[u]);
+        } else {
+            int gy = v0 + srow;
+            if ((unsigned)gy >= (unsigned)h) gy = reflect101(gy, h);  // only the strips at the image edge
+            if (!edge_x) {
+                const int gx0 = tx0 - R + sc0;
+#pragma unroll
+                for (int u = 0; u < NS; u++)
+                    if ((u + 1) * TPR <= G::COLS || sc0 + TPR * u < G::COLS) pf[u] = source(gy, gx0 + TPR * u);
             } else {
-                if (pf_row[u] >= 0) {
-                    int gy = v0 + pf_row[u];
-                    if ((unsigned)gy >= (unsigned)h) gy = reflect101(gy, h);  // only the strips at the image edge
-                    pf[u] = source(gy, pf_gx[u]);
-                }
+#pragma unroll
+                for (int u = 0; u < NS; u++)
+                    if ((u + 1) * TPR <= G::COLS || sc0 + TPR * u < G::COLS)
+                        pf[u] = source(gy, reflect101(tx0 - R + sc0 + TPR * u, w));
             }
         }
     };
     auto stage = [&](int s, double *s_in) {
         const int v0 = ys - R + MCH * s;
+        if constexpr (kQuads) {
 #pragma unroll
-        for (int u = 0; u < NSLOT; u++) {
-            if (pf_row[u] < 0) continue;
-            if constexpr (kQuads) {
+            for (int u = 0; u < NSLOT; u++) {
+                if (pf_row[u] < 0) continue;
                 const int gy = v0 + pf_row[u], gx = pf_gx[u];
                 double o[4];
                 if (source.interior(gy, gx)) {
@@ -184,9 +190,12 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                 q[1] = o[1];
                 q[G::PIN] = o[2];
                 q[G::PIN + 1] = o[3];
-            } else {
-                s_in[pf_lds[u]] = pf[u];
             }
+        } else {
+            double *q = s_in + srow * G::PIN + sc0;
+#pragma unroll
+            for (int u = 0; u < NS; u++)
+                if ((u + 1) * TPR <= G::COLS || sc0 + TPR * u < G::COLS) q[TPR * u] = pf[u];
         }
         (void)v0;
     };
