@@ -1,4 +1,4 @@
-"""The bench line: the last recorded run (profiles/r1_bench.json, written by `python bench.py` on an MI355X)
+"""The bench line: the last recorded run (profiles/r2_bench.json, written by `python bench.py` on an MI355X)
 carries every field the measurement contract names, with consistent values."""
 import json
 import os
@@ -12,7 +12,7 @@ def load(name):
 
 
 def test_recorded_bench_line_has_the_contract_fields():
-    d = load("r1_bench.json")
+    d = load("r2_bench.json")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "frames/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -26,17 +26,29 @@ def test_recorded_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.5
+    # the counters see the bytes the kernel moves (no stored difference-of-Gaussians level): 2/3 of the algorithmic figure
+    m = r["moved"]
+    assert abs(m["bytes_per_launch"] * 1.5 - r["algorithmic_bytes_per_launch"]) < 1e-6 * m["bytes_per_launch"]
+    assert r["traffic"] is None or 0.95 < r["traffic"] / m["bytes_per_launch"] < 1.25
+    for k in ("extrema_gradients", "descriptor", "base"):
+        e = d["kernels"][k]
+        assert e["bound"] and 0 < e["frac"] < 1 and abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-9
+    kn = d["knn"]
+    assert (kn["queries"], kn["train"]) == (1 << 20, 1310720)          # one GPU's share of 1 M x 10 M
+    assert kn["roofline"]["bound"] == "mfma" and kn["roofline"]["peak"] == 5000
+    kc = kn["cpu_baseline"]
+    assert kc["unit"] == "pairs/s" and kc["cores"] >= 1 and kc["value"] > 0 and kc["gpu_results_identical_on_sample"] is True
+    assert d["end_to_end"]["frames_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
 
 
 def test_rocprof_summary_agrees_with_the_event_timing():
-    """profiles/r1_bench_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of the run that wrote
-    r1_bench_profiled.json: the dominant kernel's average duration must match the HIP-event figure."""
+    """profiles/r2_bench_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of the run that wrote
+    r2_bench_profiled.json: the dominant kernel's average duration must match the HIP-event figure."""
     import csv
-    d = load("r1_bench_profiled.json")
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_bench_kernel_stats.csv"))))
+    d = load("r2_bench_profiled.json")
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv"))))
     name = d["roofline"]["kernel"].split()[0]   # k_blur_march<13>
     hit = [r for r in rows if name in r["Name"]]
     assert len(hit) == 1
