@@ -1,14 +1,17 @@
-// Counterpart of the reference's src/main.cpp (main.cpp:22-152), without the match
-// drawing: extract features of every image, then, from the last image backwards,
+// Counterpart of the reference's src/main.cpp (main.cpp:22-152): extract features of every image,
+// then, from the last image backwards,
 // match the running panorama against the next image, report the good matches,
 // estimate the homography that maps the panorama onto the image, compose the
-// two ("Final-<names>.png") and carry the result on as the new panorama.
+// two ("Final-<names>.png") and carry the result on as the new panorama.  Like the reference it
+// writes "<name>_keypoints.png" per extraction (sift.cpp:89-90) and "Matches<names>.png" per pair
+// (main.cpp:110-112); SIFT_AMD_KEYPOINT_PNG=0 turns the former off.
 // Images are PNG or binary PGM/PPM files, read by sift_io::imread with the
 // conventions of cv::imread (BGR, 8-bit, 3 channels).
 //
 //   sift_demo <image>                 -> keypoints only (main.cpp:28-39)
 //   sift_demo <img1> ... <imgN>       -> match each img against imgN
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <sstream>
 #include <vector>
@@ -24,6 +27,10 @@ static std::string stem_of(const std::string &path) {
 }
 
 int main(int argc, char **argv) {
+    {
+        const char *env = std::getenv("SIFT_AMD_KEYPOINT_PNG");
+        sift::write_keypoint_images(!(env && env[0] == '0'));
+    }
     if (argc < 2) {
         printf("usage: sift_demo <Image_Path> <Image_Path>\n");
         return -1;
@@ -76,6 +83,11 @@ int main(int argc, char **argv) {
             std::cout.precision(6);
         }
         name_ref += '+' + name;  // main.cpp:108
+        {   // main.cpp:109-112: drawMatches(ref, ref_kpt, img, kpt, good_matches, ...) + imwrite
+            std::vector<std::pair<int, int>> pairs;
+            for (const auto &gm : good) pairs.emplace_back(gm.queryIdx, gm.trainIdx);
+            sift_io::imwrite("./Matches" + name_ref + ".png", sift_io::draw_matches(ref, s_ref.keypoints, img, s.keypoints, pairs));
+        }
         if (!hr.found || img.rows > ref.rows) {
             std::cout << "no panorama for " << name_ref << std::endl;  // the reference throws here
             return 1;

@@ -2,6 +2,8 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -223,6 +225,129 @@ cv::Mat imread(const std::string &path) {
     if (buf.size() >= 4 && buf[0] == 0xFF && buf[1] == 0xD8) return decode_jpeg(buf.data(), buf.size());
     if (buf.size() >= 7 && buf[0] == 'P' && (buf[1] == '5' || buf[1] == '6')) return read_pnm(buf);
     return cv::Mat();
+}
+
+
+// ---- overlays -----------------------------------------------------------------
+
+namespace {
+
+struct Canvas {
+    cv::Mat &m;
+    void put(int x, int y, const unsigned char c[3]) {
+        if (x < 0 || y < 0 || x >= m.cols || y >= m.rows) return;
+        unsigned char *p = m.ptr<unsigned char>(y) + 3 * x;
+        p[0] = c[0];
+        p[1] = c[1];
+        p[2] = c[2];
+    }
+    void circle(int cx, int cy, int r, const unsigned char c[3]) {  // midpoint circle, one pixel wide
+        if (r <= 0) {
+            put(cx, cy, c);
+            return;
+        }
+        int x = r, y = 0, err = 1 - r;
+        while (x >= y) {
+            const int px[8] = {x, y, -y, -x, -x, -y, y, x}, py[8] = {y, x, x, y, -y, -x, -x, -y};
+            for (int k = 0; k < 8; k++) put(cx + px[k], cy + py[k], c);
+            y++;
+            if (err < 0) {
+                err += 2 * y + 1;
+            } else {
+                x--;
+                err += 2 * (y - x) + 1;
+            }
+        }
+    }
+    void line(int x0, int y0, int x1, int y1, const unsigned char c[3]) {  // Bresenham
+        const int dx = std::abs(x1 - x0), sx = x0 < x1 ? 1 : -1, dy = -std::abs(y1 - y0), sy = y0 < y1 ? 1 : -1;
+        // clip hopeless segments early: both ends far outside on the same side
+        if ((x0 < 0 && x1 < 0) || (y0 < 0 && y1 < 0) || (x0 >= m.cols && x1 >= m.cols) || (y0 >= m.rows && y1 >= m.rows)) return;
+        int err = dx + dy;
+        for (long guard = 0; guard < 4L * (dx - dy + 1); guard++) {
+            put(x0, y0, c);
+            if (x0 == x1 && y0 == y1) break;
+            const int e2 = 2 * err;
+            if (e2 >= dy) {
+                err += dy;
+                x0 += sx;
+            }
+            if (e2 <= dx) {
+                err += dx;
+                y0 += sy;
+            }
+        }
+    }
+};
+
+// one colour per item: a fixed multiplicative sequence, bright enough to show on dark and light ground
+void colour_of(unsigned index, unsigned char c[3]) {
+    unsigned s = (index + 1u) * 2654435761u;
+    for (int k = 0; k < 3; k++) {
+        s ^= s >> 15;
+        s *= 2246822519u;
+        c[k] = (unsigned char)(64 + (s >> 24) % 192);
+    }
+}
+
+cv::Mat to_bgr(const cv::Mat &image) {
+    cv::Mat out(image.rows, image.cols, CV_8UC3);
+    for (int y = 0; y < image.rows; y++) {
+        const unsigned char *src = image.ptr<unsigned char>(y);
+        unsigned char *dst = out.ptr<unsigned char>(y);
+        if (image.channels() == 3) {
+            std::memcpy(dst, src, (size_t)image.cols * 3);
+        } else {
+            for (int x = 0; x < image.cols; x++) dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = src[x];
+        }
+    }
+    return out;
+}
+
+}  // namespace
+
+cv::Mat draw_keypoints(const cv::Mat &image, const std::vector<cv::KeyPoint> &keypoints) {
+    if (image.empty() || image.depth() != CV_8U || (image.channels() != 1 && image.channels() != 3)) return cv::Mat();
+    cv::Mat out = to_bgr(image);
+    Canvas cv_{out};
+    for (size_t i = 0; i < keypoints.size(); i++) {
+        const cv::KeyPoint &k = keypoints[i];
+        unsigned char c[3];
+        colour_of((unsigned)i, c);
+        const int cx = (int)std::lrint(k.pt.x), cy = (int)std::lrint(k.pt.y), r = (int)std::lrint(k.size / 2);
+        cv_.circle(cx, cy, r, c);
+        if (k.angle != -1) {
+            const double a = k.angle * 3.14159265358979323846 / 180.0;
+            cv_.line(cx, cy, cx + (int)std::lrint(std::cos(a) * r), cy + (int)std::lrint(std::sin(a) * r), c);
+        }
+    }
+    return out;
+}
+
+cv::Mat draw_matches(const cv::Mat &a, const std::vector<cv::KeyPoint> &ka, const cv::Mat &b,
+                     const std::vector<cv::KeyPoint> &kb, const std::vector<std::pair<int, int>> &pairs) {
+    if (a.empty() || b.empty() || a.type() != CV_8UC3 || b.type() != CV_8UC3) return cv::Mat();
+    const int rows = std::max(a.rows, b.rows);
+    cv::Mat out(rows, a.cols + b.cols, CV_8UC3);
+    for (int y = 0; y < rows; y++) {
+        unsigned char *dst = out.ptr<unsigned char>(y);
+        std::memset(dst, 0, (size_t)out.cols * 3);
+        if (y < a.rows) std::memcpy(dst, a.ptr<unsigned char>(y), (size_t)a.cols * 3);
+        if (y < b.rows) std::memcpy(dst + (size_t)a.cols * 3, b.ptr<unsigned char>(y), (size_t)b.cols * 3);
+    }
+    Canvas cv_{out};
+    for (size_t i = 0; i < pairs.size(); i++) {
+        if (pairs[i].first < 0 || pairs[i].first >= (int)ka.size() || pairs[i].second < 0 || pairs[i].second >= (int)kb.size()) continue;
+        unsigned char c[3];
+        colour_of((unsigned)i, c);
+        const cv::KeyPoint &p = ka[(size_t)pairs[i].first], &q = kb[(size_t)pairs[i].second];
+        const int x0 = (int)std::lrint(p.pt.x), y0 = (int)std::lrint(p.pt.y);
+        const int x1 = a.cols + (int)std::lrint(q.pt.x), y1 = (int)std::lrint(q.pt.y);
+        cv_.circle(x0, y0, 3, c);
+        cv_.circle(x1, y1, 3, c);
+        cv_.line(x0, y0, x1, y1, c);
+    }
+    return out;
 }
 
 }  // namespace sift_io

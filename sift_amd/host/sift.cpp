@@ -12,6 +12,7 @@
 #include <mutex>
 #include <stdexcept>
 
+#include "image_io.hpp"
 #include "sift_amd.h"
 
 namespace sift {
@@ -33,7 +34,24 @@ sift_ctx *context() {
     return ctx;
 }
 
+// -1: not decided yet (the environment is consulted on first use)
+int g_keypoint_png = -1;
+
+bool keypoint_png_enabled() {
+    if (g_keypoint_png < 0) {
+        const char *env = std::getenv("SIFT_AMD_KEYPOINT_PNG");
+        g_keypoint_png = env && env[0] == '1';
+    }
+    return g_keypoint_png != 0;
+}
+
 }  // namespace
+
+bool write_keypoint_images(bool on) {
+    const bool before = keypoint_png_enabled();
+    g_keypoint_png = on;
+    return before;
+}
 
 // sift.cpp:26-46: gray conversion, onex, octave count, and the base image (2x upsample + blur, on the GPU).
 sift_handler::sift_handler(std::string _name, cv::Mat &&_base) : name(std::move(_name)) {
@@ -99,6 +117,10 @@ void sift_handler::exec() {
         descriptors.emplace_back(res.descriptors + (size_t)i * 128, res.descriptors + (size_t)(i + 1) * 128);
     }
     sift_result_free(&res);
+    if (keypoint_png_enabled()) {  // sift.cpp:89-90: drawKeypoints(onex as 8-bit, keypoints, DRAW_RICH_KEYPOINTS) + imwrite
+        cv::Mat gray(height_, width_, CV_8UC1, gray_.data());
+        sift_io::imwrite(name + "_keypoints.png", sift_io::draw_keypoints(gray, keypoints));
+    }
     std::cerr << "Keypoints Calculated: " << keypoints.size() << "\n";
     dump_keypoints();
     std::cerr << "Completed SIFT for " << name << "\n\n";

@@ -8,12 +8,14 @@
 //   s.keypoints;                                              // sift.hpp:93
 //
 // Differences from the reference, all outside the numeric results:
-//   * `base` (sift.hpp:90) is filled by exec(), not by the constructor;
 //   * get() on zero keypoints returns an empty 0 x 128 matrix instead of
 //     indexing descriptors[0] (sift.cpp:105);
-//   * "<name>_keypoints.png" (sift.cpp:89-90) is written only when the real
-//     OpenCV is available; "<name>.csv" (sift.cpp:114-121) and the stderr lines
-//     (sift.cpp:37-38, 69, 93, 96 and the TIMEIT lines) are always produced;
+//   * "<name>_keypoints.png" (sift.cpp:89-90) is written only on request
+//     (sift::write_keypoint_images(true), or SIFT_AMD_KEYPOINT_PNG=1 in the
+//     environment): encoding a PNG costs ten times the extraction of the frame.
+//     Its circles are not anti-aliased and its colours are not OpenCV's.
+//     "<name>.csv" (sift.cpp:114-121) and the stderr lines (sift.cpp:37-38, 69,
+//     93, 96 and the TIMEIT lines) are always produced;
 //   * errors of the GPU library surface as std::runtime_error.
 #ifndef SIFT_H
 #define SIFT_H
@@ -73,6 +75,10 @@ class sift_handler {
     std::vector<unsigned char> gray_;  // 8-bit gray input, row-major
     int width_ = 0, height_ = 0;
 };
+
+// Whether exec() writes "<name>_keypoints.png" (sift.cpp:89-90).  Off unless SIFT_AMD_KEYPOINT_PNG=1 is set when
+// the first handler runs; returns the previous setting.
+bool write_keypoint_images(bool on);
 
 // Matcher used in place of cv::FlannBasedMatcher (main.cpp:48-51, 75): exact
 // top-2 nearest neighbours on the GPU.  query/train are N x 128 CV_32FC1

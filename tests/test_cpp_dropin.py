@@ -95,6 +95,11 @@ def test_demo_matches_oracle(sift_lib, oracle, lenna_bgr, lenna_rotated_bgr, gol
     assert rows.shape == (1112, 4)
     for col, f in enumerate(("x", "y", "size", "angle")):
         assert np.allclose(rows[:, col], ref[f], rtol=1e-5, atol=0)
+    # the pictures the reference writes beside it: "<name>_keypoints.png" (sift.cpp:89-90), "Matches<names>.png" (main.cpp:110-112)
+    from PIL import Image
+    assert Image.open(tmp_path / "Lenna_keypoints.png").size == (512, 512)
+    assert Image.open(tmp_path / "LennaRotated_keypoints.png").size == (512, 512)
+    assert Image.open(tmp_path / "MatchesLenna+LennaRotated.png").size == (1024, 512)
     # matches: query = reference image (Lenna, last argument), train = the other (main.cpp:75)
     q, t = golden("lenna")["descriptors"], golden("lennarotated")["descriptors"]
     i1, d1, i2, d2, acc = oracle.knn2_u8(q, t, threads=8)

@@ -255,3 +255,27 @@ def test_mutated_files_do_not_break_the_decoders(tmp_path):
     for i in range(0, len(paths), 100):
         r = subprocess.run([exe] + paths[i:i + 100], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_keypoint_and_match_overlays(tmp_path):
+    """The stand-ins for cv::drawKeypoints(DRAW_RICH_KEYPOINTS) (sift.cpp:89) and cv::drawMatches (main.cpp:110),
+    built with the address and undefined-behaviour sanitizers: circles and lines partly or wholly outside the
+    canvas are clipped, the gray ground is kept, coloured pixels appear, and both pictures are valid PNG files."""
+    from PIL import Image
+    exe = str(tmp_path / "draw_check")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++20", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I" + HOST, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "draw_check.cpp"),
+                           os.path.join(HOST, "image_io.cpp"), os.path.join(HOST, "jpeg_decode.cpp"), "-lz", "-o", exe])
+    a, b = tmp_path / "kp.png", tmp_path / "m.png"
+    out = subprocess.run([exe, str(a), str(b)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["160", "120", "320", "120"]
+    kp, m = np.array(Image.open(a)), np.array(Image.open(b))
+    assert kp.shape == (120, 160, 3) and m.shape == (120, 320, 3)
+    yy, xx = np.mgrid[0:120, 0:160]
+    gray = ((xx + yy) % 256).astype(np.uint8)
+    coloured = (kp[:, :, 0] != kp[:, :, 1]) | (kp[:, :, 1] != kp[:, :, 2])
+    assert 200 < coloured.sum() < 2000                       # three outlines and two radii, one pixel wide
+    assert np.array_equal(kp[~coloured][:, 0], gray[~coloured])
+    assert coloured[50, 40 + 15] or coloured[50, 40 - 15]    # the circle of radius size/2 = 15 round (40, 50)
+    both = (m[:, :, 0] != m[:, :, 1]) | (m[:, :, 1] != m[:, :, 2])
+    assert both.sum() > coloured.sum() * 2                   # two copies of the overlay plus the match lines
