@@ -225,7 +225,9 @@ int sift_match_min_dist_filter(const sift_knn2 *knn, int nq, int32_t *good_idx, 
 /* The reference is one C++ program (main.cpp:22-152); a group lets such a program spread the two stages that shard
  * over several GPUs without leaving the process: frames are independent (contiguous blocks of frames per GPU, no
  * collective), and the matcher's train set is cut into contiguous shards whose per-GPU top-2 results are exchanged
- * with RCCL and merged.  A group borrows its contexts (one per GPU, all distinct GPUs); they must outlive it.
+ * with RCCL and merged.  A group borrows its contexts, normally one per GPU; they must outlive it.  (Several
+ * contexts of one GPU may share a group for sift_extract_batch_u8, which then splits the frames between them;
+ * sift_knn2_sharded requires distinct GPUs.)
  * Calls on a group must not overlap with other calls on its contexts. */
 typedef struct sift_group sift_group;
 int sift_group_create(sift_ctx *const *ctxs, int ngpu, sift_group **out);

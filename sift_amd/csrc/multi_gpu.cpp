@@ -269,7 +269,7 @@ int sift_group_create(sift_ctx *const *ctxs, int ngpu, sift_group **out) {
     for (int i = 0; i < ngpu; i++) {
         if (!ctxs[i]) return fail(SIFT_ERR_INVALID, "NULL context");
         for (int j = 0; j < i; j++)
-            if (ctxs[j]->device == ctxs[i]->device) return fail(SIFT_ERR_INVALID, "two contexts of a group share a GPU");
+            if (ctxs[j] == ctxs[i]) return fail(SIFT_ERR_INVALID, "a context appears twice in the group");
     }
     sift_group *g = new sift_group();
     g->ctx.assign(ctxs, ctxs + ngpu);
@@ -361,6 +361,11 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
     for (size_t i = 0; i < (size_t)nt * 128; i++)
         if (t[i] > 127) return fail(SIFT_ERR_NOT_INTEGRAL, "train descriptor value above 127");
     const int ngpu = (int)g->ctx.size();
+    // one communicator rank per GPU: members that share a GPU can split frames between them, not a train set
+    for (int i = 0; i < ngpu; i++)
+        for (int j = 0; j < i; j++)
+            if (g->ctx[j]->device == g->ctx[i]->device)
+                return fail(SIFT_ERR_INVALID, "sift_knn2_sharded needs every context of the group on a GPU of its own");
     int rc = load_rccl(g->rccl);
     if (rc) return rc;
     if (g->comms.empty()) {

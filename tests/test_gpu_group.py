@@ -57,6 +57,32 @@ def test_batch_extraction_from_host_frames_equals_single_calls(sift_lib, ctx, gr
     sift_lib.lib().sift_frame_results_free(res, n)
 
 
+def test_frames_split_over_two_members_driven_by_two_host_threads(sift_lib, ctx):
+    """Two contexts in one group (both on the only GPU of this box): the frames are cut into two contiguous blocks,
+    each driven by its own host thread and pipeline, and every result lands at its frame's index.  The matcher
+    refuses such a group: its exchange needs one communicator rank per GPU."""
+    w, h, n = 320, 240, 9
+    frames = np.stack([sift_lib.synth_dead_leaves(7, i, w, h) for i in range(n)])
+    want = [ctx.extract(f) for f in frames]
+    other = sift_lib.Context(0)
+    g = sift_lib.Group([ctx, other])
+    try:
+        assert sift_lib.shard_bounds(n, 2) == [0, 4, 9]
+        for per_launch in (2, 16):
+            got = g.extract_batch(frames, per_launch)
+            for (kp, desc, _), (wkp, wdesc, _) in zip(got, want):
+                assert np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
+        got = g.extract_batch(frames[:1], 4)               # fewer frames than members: one of them gets none
+        assert np.array_equal(got[0][0], want[0][0])
+        with pytest.raises(sift_lib.SiftError):
+            g.knn2(np.zeros((4, 128), np.uint8), np.zeros((4, 128), np.uint8))
+        with pytest.raises(sift_lib.SiftError):
+            sift_lib.Group([ctx, ctx])
+    finally:
+        g.close()
+        other.close()
+
+
 def test_batch_extraction_reruns_frames_that_overflow_their_lists(sift_lib, ctx, oracle, lenna_bgr):
     gray = oracle.bgr_to_gray(lenna_bgr)
     frames = np.stack([gray, gray[::-1].copy()])
