@@ -84,6 +84,11 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
     unsigned n_samples = 0, n_atomics = 0;  // COUNT only; per lane, per keypoint (a window holds < 2^17 samples)
     // Keypoints are pulled from a per-frame cursor: window areas differ by a factor of 25 between keypoints, and a
     // fixed round-robin deal of keypoints to workgroups measured 4 % slower than the cursor's dynamic balance.
+    // The list is sorted by x across all octaves, so concurrent workgroups sample unrelated windows and every sample
+    // row is an L2 miss.  Processing the keypoints in (octave, layer, 128-pixel tile) order instead, one eighth of
+    // the order per XCD, was measured: L2 misses per 16 frames fell from 317 M to 144 M and the kernel took 14.65 ms
+    // per 64 frames against 14.27 ms (plus 0.19 ms for the ordering pass): the kernel waits for its LDS atomics,
+    // not for memory, so the list order stays.
     for (;;) {
         if (tid == 0) sm.idx = atomicAdd(&cursors[f], 1);
         for (int t = tid; t < NCOPY * CSTRIDE; t += NT) (&sm.tensor[0][0])[t] = 0.0;
@@ -185,7 +190,8 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
                     for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
                         const int j = jlo[r] + c + lane;
                         const int yy = min(max(pt_y + i0 + r * NWAVES, 0), height - 1);
-                        const int xx = min(max(pt_x + j, 0), width - 1);
+                        // lanes past the end of their row's interval re-read its last sample instead of the memory behind it
+                        const int xx = min(max(pt_x + min(j, jhi[r]), 0), width - 1);
                         g[r] = image[(size_t)yy * width + xx];  // sift.cpp:507-510
                         wj[r] = sm.wtab[min(abs(j), 255)];
                     }

@@ -30,18 +30,19 @@ namespace sa {
 
 namespace {
 
-// Strip geometry.  Filters up to 21 taps use 128-column strips walked 16 rows at a time
-// (1 KB contiguous per row: fewer, longer bursts and half the column halo); the 27-tap filter
-// is bound by its arithmetic and takes the same time either way (3.70 ms per 64 1080p frames with
-// 128 x 16 and with 64 x 32); it keeps 64 columns x 32 rows, the smaller LDS footprint.
+// Strip geometry.  Filters up to 17 taps use 128-column strips walked 16 rows at a time
+// (1 KB contiguous per row: fewer, longer bursts and half the column halo).  The 21- and 27-tap
+// filters are bound by their arithmetic and need three workgroups per CU to hide it: 64 columns
+// x 32 rows keeps their LDS footprint under a third of the CU's 160 KB (the 21-tap filter's
+// 128 x 16 tile is 56 KB and fits only twice; 3.14 -> 2.90 ms per 64 1080p frames).
 
 // Threads per workgroup: 256 (8 consecutive outputs per thread in either pass) for the short
 // filters, 512 (4 outputs per thread, half the registers, twice the waves per SIMD) for the
 // long ones, whose loops are bound by fp64 issue and need the extra waves to stay busy.
 template <int R>
 struct MarchGeom {
-    static constexpr int TW = R <= 10 ? 128 : 64;   // strip width (outputs)
-    static constexpr int MCH = R <= 10 ? 16 : 32;   // rows per step
+    static constexpr int TW = R <= 8 ? 128 : 64;   // strip width (outputs)
+    static constexpr int MCH = R <= 8 ? 16 : 32;   // rows per step
     static constexpr int NTHREADS = 512;
     static constexpr int CX = TW / (NTHREADS / MCH);   // consecutive outputs per thread in the row pass
     static constexpr int CY = MCH / (NTHREADS / TW);   // consecutive outputs per thread in the column pass
@@ -110,6 +111,14 @@ struct UpsampleSource {
         return r0 * (1.0 - fy) + r1 * fy;
     }
 };
+
+// Keeps the chunked LDS reads of the filter passes where they are written: the memory clobber stops instruction
+// selection from gathering every read of a pass at its top (reads are free to move across a scheduling barrier when
+// the instruction order is first laid down), the scheduling barrier stops the machine scheduler from doing the same.
+__device__ __forceinline__ void stream_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // grid: (strips, vertical segments, frames).  `nxt` may be null.
 template <int R, class Source>
@@ -217,7 +226,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
             // every output m it belongs to, so each output still accumulates its taps left to right.  The
             // scheduling barriers keep the compiler from hoisting every read to the top (which costs 2(CX+2R)
             // registers and a third of the waves).
-            constexpr int NEL = CX + 2 * R, ECH = 8, NCH = (NEL + ECH - 1) / ECH;
+            constexpr int NEL = CX + 2 * R, ECH = 4, NCH = (NEL + ECH - 1) / ECH;
             double acc[CX];
             double buf[2][ECH];
 #pragma unroll
@@ -229,7 +238,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                     for (int u = 0; u < ECH; u++)
                         if ((c + 1) * ECH + u < NEL) buf[(c + 1) & 1][u] = p[(c + 1) * ECH + u];
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                stream_fence();
 #pragma unroll
                 for (int u = 0; u < ECH; u++) {
                     const int k = c * ECH + u;
@@ -242,7 +251,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                         else if (t > 0 && t <= 2 * R) acc[m] += taps.c[t] * vk;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                stream_fence();
             }
 #pragma unroll
             for (int m = 0; m < CX; m++) q[m] = acc[m];
@@ -267,7 +276,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                 // upper and lower operands of the CY outputs at step t are two windows of CY elements that slide
                 // outwards by one element per step, so the column is streamed through registers too: TCH steps'
                 // worth of new elements are read one chunk ahead of their use.
-                constexpr int TCH = 4, NTC = (R + TCH - 1) / TCH;
+                constexpr int TCH = 2, NTC = (R + TCH - 1) / TCH;
                 double acc[CY], hi_w[CY], lo_w[CY];
                 {
                     double cen[CY];
@@ -304,7 +313,7 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                             }
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    stream_fence();
 #pragma unroll
                     for (int u = 0; u < TCH; u++) {
                         const int t = 1 + c * TCH + u;
@@ -320,7 +329,11 @@ __device__ __forceinline__ void march(const Source source, double *__restrict__ 
                             lo_w[0] = fresh_lo[c & 1][u];
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    // the sums so far are pinned here, otherwise the arithmetic of every chunk sinks below the last
+                    // read and all 2R + CY elements are live at once
+#pragma unroll
+                    for (int m = 0; m < CY; m++) asm volatile("" : "+v"(acc[m]));
+                    stream_fence();
                 }
 #pragma unroll
                 for (int m = 0; m < CY; m++) {
