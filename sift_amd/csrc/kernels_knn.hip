@@ -17,8 +17,8 @@
 // queries are the columns (B operand, held in registers for the whole scan), so
 // a lane owns one query and its 16 accumulator registers are 16 train rows.
 // The common case costs a 16-way integer min and one compare per 32x32 block:
-// only when some lane's minimum beats its current second-best does the wave
-// take the exact update path.  Ties resolve to the smaller train index.
+// only when some lane's minimum beats its current second-best is the block
+// recomputed and taken through the exact update path.  Ties resolve to the smaller train index.
 #include <limits.h>
 
 #include <mutex>
@@ -68,15 +68,6 @@ __global__ void k_train_bias(const uint8_t *__restrict__ t, int nt, int *__restr
     bias[r] = sq - C_OFF * sum;
 }
 
-__device__ __forceinline__ int min16(const v16i &a) {
-    int m0 = min(min(a[0], a[1]), a[2]);
-    int m1 = min(min(a[3], a[4]), a[5]);
-    int m2 = min(min(a[6], a[7]), a[8]);
-    int m3 = min(min(a[9], a[10]), a[11]);
-    int m4 = min(min(a[12], a[13]), a[14]);
-    return min(min(min(m0, m1), min(m2, m3)), min(m4, a[15]));
-}
-
 // (s, idx) lexicographic "a before b"
 __device__ __forceinline__ bool before(int sa_, int ia, int sb, int ib) {
     return sa_ < sb || (sa_ == sb && (unsigned)ia < (unsigned)ib);  // idx -1 sorts last
@@ -92,7 +83,7 @@ __device__ __forceinline__ void top2_insert(int s, int idx, int &b1, int &i1, in
 
 // grid.x = query blocks, grid.y = train splits (each split scans a contiguous
 // range of tiles and writes its own partial result row).
-__global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
+__global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
                                                int nt, const int *__restrict__ tbias, int train_base,
                                                int tiles_per_split, sift_knn2 *__restrict__ out) {
     __shared__ uint4 s_tile[2][TT * 8];
@@ -180,63 +171,177 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t *__restrict__ q, int
     for (int tile = tile_begin; tile < tile_end; tile++) {
         const int buf = (tile - tile_begin) & 1;
         if (tile + 1 < tile_end) fetch(tile + 1);
+        // Fast pass over the tile, free of branches.  A (block, query block) pair in which some lane's minimum
+        // beats that lane's threshold only sets a bit; the rare pairs that did are recomputed below.  The
+        // thresholds do not move during the pass, so a bit may be set for a row that an update earlier in the
+        // same tile would have excluded; the exact pass then finds nothing to insert for it.
+        //
+        // The pass is software-pipelined by hand, one scheduling fence per MFMA: in the shadow of each MFMA the
+        // wave issues either two LDS reads of the next block's operands or a third of one chain's 16-way
+        // minimum (three vector instructions), and a chain's minimum is only started two MFMAs after the
+        // chain's last one, when its result has left the matrix pipe.  MFMA order within a block of four
+        // chains c0..c3 (one per 32-query block): c0.1 c1.1 c2.1 | c0.2-4 | c3.1 | c1.2-4 | c2.2-4 | c3.2-4, so that
+        // the bias registers (the C operand of each chain's first MFMA) are free for the next block's after the
+        // seventh MFMA and chain c3 of the previous block can be reduced under the first six.
+        auto load_af = [&](int rb, int ks, v4i &dst) {
+            const int row = rb * 32 + c, chunk = ks * 2 + h;
+            const uint4 a = s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))];
+            dst = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+        };
+        auto load_bias = [&](int rb, int g, v16i &cinit) {
+            const int4 bb = *reinterpret_cast<const int4 *>(&s_bias[buf][rb * 32 + 8 * g + 4 * h]);
+            cinit[4 * g + 0] = bb.x;
+            cinit[4 * g + 1] = bb.y;
+            cinit[4 * g + 2] = bb.z;
+            cinit[4 * g + 3] = bb.w;
+        };
+        auto half_min = [](const v16i &a, int o, int &x, int &y) {  // three instructions: min of 8 left in two
+            const int t = min(min(a[o], a[o + 1]), a[o + 2]);
+            x = min(min(a[o + 3], a[o + 4]), a[o + 5]);
+            y = min(min(a[o + 6], a[o + 7]), t);
+            asm volatile("" : "+v"(x), "+v"(y));  // evaluated here, not where the values are consumed
+        };
+        unsigned hits = 0;  // bit rb * QB + qb; the same in every lane
+        auto finish = [&](int x1, int y1, int x2, int y2, int threshold, unsigned bit) {
+            const int m = min(min(min(x1, y1), x2), y2);
+            hits |= __ballot(m < threshold) != 0 ? bit : 0u;
+        };
+        static_assert(QB == 4, "the schedule below is written for four chains");
+        constexpr int NB = TT / 32;
+        v4i af[4], afn[4];
+        v16i cinit;
+        v16i acc[QB];
+        int lo2[2], hi2[2], lo3[2], hi3[2];  // halves of the minima of chains 2 and 3, carried into the next block
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) load_af(0, ks, af[ks]);
+#pragma unroll
+        for (int g = 0; g < 4; g++) load_bias(0, g, cinit);
+#define SA_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define SA_MFMA(qb, ks, cin) acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bf[qb][ks], cin, 0, 0, 0)
+#pragma unroll
+        for (int rb = 0; rb < NB; rb++) {
+            const bool prev = rb > 0, more = rb + 1 < NB;
+            int lo0[2], hi0[2], lo1[2], hi1[2];
+            SA_FENCE();
+            SA_MFMA(0, 0, cinit);
+            SA_FENCE();
+            if (prev) finish(lo2[0], lo2[1], hi2[0], hi2[1], thr[2], 1u << ((rb - 1) * QB + 2));
+            SA_FENCE();
+            SA_MFMA(1, 0, cinit);
+            SA_FENCE();
+            if (more) {
+                load_af(rb + 1, 0, afn[0]);
+                load_af(rb + 1, 1, afn[1]);
+            }
+            SA_FENCE();
+            SA_MFMA(2, 0, cinit);
+            SA_FENCE();
+            if (prev) half_min(acc[3], 0, lo3[0], lo3[1]);
+            SA_FENCE();
+            SA_MFMA(0, 1, acc[0]);
+            SA_FENCE();
+            if (prev) half_min(acc[3], 8, hi3[0], hi3[1]);
+            SA_FENCE();
+            SA_MFMA(0, 2, acc[0]);
+            SA_FENCE();
+            if (prev) finish(lo3[0], lo3[1], hi3[0], hi3[1], thr[3], 1u << ((rb - 1) * QB + 3));
+            SA_FENCE();
+            SA_MFMA(0, 3, acc[0]);
+            SA_FENCE();
+            if (more) {
+                load_af(rb + 1, 2, afn[2]);
+                load_af(rb + 1, 3, afn[3]);
+            }
+            SA_FENCE();
+            SA_MFMA(3, 0, cinit);
+            SA_FENCE();
+            if (more) {
+                load_bias(rb + 1, 0, cinit);
+                load_bias(rb + 1, 1, cinit);
+            }
+            SA_FENCE();
+            SA_MFMA(1, 1, acc[1]);
+            SA_FENCE();
+            if (more) {
+                load_bias(rb + 1, 2, cinit);
+                load_bias(rb + 1, 3, cinit);
+            }
+            SA_FENCE();
+            SA_MFMA(1, 2, acc[1]);
+            SA_FENCE();
+            half_min(acc[0], 0, lo0[0], lo0[1]);
+            SA_FENCE();
+            SA_MFMA(1, 3, acc[1]);
+            SA_FENCE();
+            half_min(acc[0], 8, hi0[0], hi0[1]);
+            SA_FENCE();
+            SA_MFMA(2, 1, acc[2]);
+            SA_FENCE();
+            finish(lo0[0], lo0[1], hi0[0], hi0[1], thr[0], 1u << (rb * QB + 0));
+            SA_FENCE();
+            SA_MFMA(2, 2, acc[2]);
+            SA_FENCE();
+            half_min(acc[1], 0, lo1[0], lo1[1]);
+            SA_FENCE();
+            SA_MFMA(2, 3, acc[2]);
+            SA_FENCE();
+            half_min(acc[1], 8, hi1[0], hi1[1]);
+            SA_FENCE();
+            SA_MFMA(3, 1, acc[3]);
+            SA_FENCE();
+            finish(lo1[0], lo1[1], hi1[0], hi1[1], thr[1], 1u << (rb * QB + 1));
+            SA_FENCE();
+            SA_MFMA(3, 2, acc[3]);
+            SA_FENCE();
+            half_min(acc[2], 0, lo2[0], lo2[1]);
+            SA_FENCE();
+            SA_MFMA(3, 3, acc[3]);
+            SA_FENCE();
+            half_min(acc[2], 8, hi2[0], hi2[1]);
+            SA_FENCE();
+            if (more) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) af[ks] = afn[ks];
+            }
+        }
+        finish(lo2[0], lo2[1], hi2[0], hi2[1], thr[2], 1u << ((NB - 1) * QB + 2));
+        half_min(acc[3], 0, lo3[0], lo3[1]);
+        half_min(acc[3], 8, hi3[0], hi3[1]);
+        finish(lo3[0], lo3[1], hi3[0], hi3[1], thr[3], 1u << ((NB - 1) * QB + 3));
+        SA_FENCE();
+#undef SA_MFMA
+#undef SA_FENCE
+        if (hits) {
 #pragma unroll 1
-        for (int rb = 0; rb < TT / 32; rb++) {
-            v16i cinit;
+            for (int rb = 0; rb < TT / 32; rb++) {
+                if (!((hits >> (rb * QB)) & ((1u << QB) - 1u))) continue;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int4 bb = *reinterpret_cast<const int4 *>(&s_bias[buf][rb * 32 + 8 * g + 4 * h]);
-                cinit[4 * g + 0] = bb.x;
-                cinit[4 * g + 1] = bb.y;
-                cinit[4 * g + 2] = bb.z;
-                cinit[4 * g + 3] = bb.w;
-            }
-            v4i af[4];
-            const int row = rb * 32 + c;
+                for (int ks = 0; ks < 4; ks++) load_af(rb, ks, af[ks]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const int chunk = ks * 2 + h;
-                const uint4 a = s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))];
-                af[ks] = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
-            }
-            // all QB accumulation chains first, then the checks, so that no check
-            // waits on the matrix pipeline
-            v16i acc[QB];
-#pragma unroll
-            for (int qb = 0; qb < QB; qb++) {
-                acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[qb][0], cinit, 0, 0, 0);
-#pragma unroll
-                for (int ks = 1; ks < 4; ks++)
-                    acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bf[qb][ks], acc[qb], 0, 0, 0);
-            }
-            bool hit[QB];
-            bool any_hit = false;
-#pragma unroll
-            for (int qb = 0; qb < QB; qb++) {
-                hit[qb] = min16(acc[qb]) < thr[qb];
-                any_hit |= hit[qb];
-            }
-            if (__any(any_hit)) {
+                for (int g = 0; g < 4; g++) load_bias(rb, g, cinit);
                 const int idx0 = tile * TT + rb * 32 + 4 * h;
 #pragma unroll
                 for (int qb = 0; qb < QB; qb++) {
-                    if (__any(hit[qb])) {
+                    if (!((hits >> (rb * QB + qb)) & 1u)) continue;
+                    v16i again = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[qb][0], cinit, 0, 0, 0);
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int sv = acc[qb][r];
-                            // most rows lose against the running second-best in every lane: skip them whole
-                            if (__any(sv < thr[qb])) {
-                                const int idx = idx0 + (r & 3) + 8 * (r >> 2);
-                                if (sv < b1[qb]) {
-                                    b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = sv; i1[qb] = idx;
-                                } else if (sv < b2[qb]) {
-                                    b2[qb] = sv; i2[qb] = idx;
-                                }
+                    for (int ks = 1; ks < 4; ks++)
+                        again = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bf[qb][ks], again, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int sv = again[r];
+                        // most rows lose against the running second-best in every lane: skip them whole
+                        if (__any(sv < thr[qb])) {
+                            const int idx = idx0 + (r & 3) + 8 * (r >> 2);
+                            if (sv < b1[qb]) {
+                                b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = sv; i1[qb] = idx;
+                            } else if (sv < b2[qb]) {
+                                b2[qb] = sv; i2[qb] = idx;
                             }
                         }
-                        const int p1 = __shfl_xor(b1[qb], 32), p2 = __shfl_xor(b2[qb], 32);
-                        thr[qb] = min(max(b1[qb], p1), min(b2[qb], p2));
                     }
+                    const int p1 = __shfl_xor(b1[qb], 32), p2 = __shfl_xor(b2[qb], 32);
+                    thr[qb] = min(max(b1[qb], p1), min(b2[qb], p2));
                 }
             }
         }
