@@ -214,13 +214,28 @@ int pipe_run(sift_ctx *ctx, Pipe &p, const ExtractJob &job) {
         // page-locked staging of chunk k (the transfer of chunk k-2 out of this buffer has completed: its run was
         // waited for when its results were taken)
         char *stage = static_cast<char *>(p.pin_up[slot]);
-        for (int i = 0; i < m; i++) {
-            const uint8_t *src = job.frames + (size_t)(first + i) * job.frame_stride;
-            if (job.row_stride == (size_t)p.w) {
-                std::memcpy(stage + (size_t)i * px, src, px);
-            } else {
-                for (int y = 0; y < p.h; y++) std::memcpy(stage + (size_t)i * px + (size_t)y * p.w, src + job.row_stride * y, (size_t)p.w);
+        auto stage_frames = [&](int i0, int i1) {
+            for (int i = i0; i < i1; i++) {
+                const uint8_t *src = job.frames + (size_t)(first + i) * job.frame_stride;
+                if (job.row_stride == (size_t)p.w) {
+                    std::memcpy(stage + (size_t)i * px, src, px);
+                } else {
+                    for (int y = 0; y < p.h; y++)
+                        std::memcpy(stage + (size_t)i * px + (size_t)y * p.w, src + job.row_stride * y, (size_t)p.w);
+                }
             }
+        };
+        // One thread copies about 10 GB/s, i.e. 13 ms for 64 1080p frames, and nothing runs on the GPU while the
+        // first chunk is staged: large chunks are copied by four threads.
+        const int helpers = (size_t)m * px >= ((size_t)32 << 20) ? std::min(3, m - 1) : 0;
+        if (helpers > 0) {
+            std::vector<std::thread> th;
+            const int per = (m + helpers) / (helpers + 1);
+            for (int t = 1; t <= helpers; t++) th.emplace_back(stage_frames, std::min(m, t * per), std::min(m, (t + 1) * per));
+            stage_frames(0, std::min(m, per));
+            for (auto &t : th) t.join();
+        } else {
+            stage_frames(0, m);
         }
         HIP_TRY(hipMemcpyAsync(b->d_frames, stage, (size_t)m * px, hipMemcpyHostToDevice, p.up));
         HIP_TRY(hipEventRecord(p.ev_up[slot], p.up));
