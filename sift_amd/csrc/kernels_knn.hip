@@ -17,8 +17,8 @@
 // queries are the columns (B operand, held in registers for the whole scan), so
 // a lane owns one query and its 16 accumulator registers are 16 train rows.
 // The common case costs a 16-way integer min and one compare per 32x32 block:
-// only when some lane's minimum beats its current second-best is the block
-// recomputed and taken through the exact update path.  Ties resolve to the smaller train index.
+// only when some lane's minimum beats its current second-best does the block's
+// accumulator go through the exact update path.  Ties resolve to the smaller train index.
 #include <limits.h>
 
 #include <mutex>
@@ -171,10 +171,9 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
     for (int tile = tile_begin; tile < tile_end; tile++) {
         const int buf = (tile - tile_begin) & 1;
         if (tile + 1 < tile_end) fetch(tile + 1);
-        // Fast pass over the tile, free of branches.  A (block, query block) pair in which some lane's minimum
-        // beats that lane's threshold only sets a bit; the rare pairs that did are recomputed below.  The
-        // thresholds do not move during the pass, so a bit may be set for a row that an update earlier in the
-        // same tile would have excluded; the exact pass then finds nothing to insert for it.
+        // Pass over the tile.  A chain's accumulator goes through the exact update only when some lane's minimum
+        // of its 16 rows beats that lane's threshold (a wave-uniform branch, rarely taken once the thresholds
+        // have tightened); the accumulator is still live at that point, so nothing is recomputed.
         //
         // The pass is software-pipelined by hand, one scheduling fence per MFMA: in the shadow of each MFMA the
         // wave issues either two LDS reads of the next block's operands or a third of one chain's 16-way
@@ -201,10 +200,32 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
             y = min(min(a[o + 6], a[o + 7]), t);
             asm volatile("" : "+v"(x), "+v"(y));  // evaluated here, not where the values are consumed
         };
-        unsigned hits = 0;  // bit rb * QB + qb; the same in every lane
-        auto finish = [&](int x1, int y1, int x2, int y2, int threshold, unsigned bit) {
+        // Exact update of query block qb with the 16 rows a lane holds of train block rb (still in the chain's
+        // accumulator when its minimum is known), row by row in ascending order (a lane's first of equal
+        // distances stays) with a wave vote per row; then the two lanes of each query exchange their best two
+        // for the new threshold.  Visiting only the row groups whose partial minimum qualifies, and exchanging
+        // through v_permlane32_swap instead of LDS, measured the same (26.1 against 25.8 ms).
+        auto exact_update = [&](const v16i &a, int qb, int rb) {
+            const int idx0 = tile * TT + rb * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int sv = a[r];
+                // most rows lose against the running second-best in every lane: skip them whole
+                if (__any(sv < thr[qb])) {
+                    const int idx = idx0 + (r & 3) + 8 * (r >> 2);
+                    if (sv < b1[qb]) {
+                        b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = sv; i1[qb] = idx;
+                    } else if (sv < b2[qb]) {
+                        b2[qb] = sv; i2[qb] = idx;
+                    }
+                }
+            }
+            const int p1 = __shfl_xor(b1[qb], 32), p2 = __shfl_xor(b2[qb], 32);
+            thr[qb] = min(max(b1[qb], p1), min(b2[qb], p2));
+        };
+        auto finish = [&](int x1, int y1, int x2, int y2, const v16i &a, int qb, int rb) {
             const int m = min(min(min(x1, y1), x2), y2);
-            hits |= __ballot(m < threshold) != 0 ? bit : 0u;
+            if (__any(m < thr[qb])) exact_update(a, qb, rb);
         };
         static_assert(QB == 4, "the schedule below is written for four chains");
         constexpr int NB = TT / 32;
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
             SA_FENCE();
             SA_MFMA(0, 0, cinit);
             SA_FENCE();
-            if (prev) finish(lo2[0], lo2[1], hi2[0], hi2[1], thr[2], 1u << ((rb - 1) * QB + 2));
+            if (prev) finish(lo2[0], lo2[1], hi2[0], hi2[1], acc[2], 2, rb - 1);
             SA_FENCE();
             SA_MFMA(1, 0, cinit);
             SA_FENCE();
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
             SA_FENCE();
             SA_MFMA(0, 2, acc[0]);
             SA_FENCE();
-            if (prev) finish(lo3[0], lo3[1], hi3[0], hi3[1], thr[3], 1u << ((rb - 1) * QB + 3));
+            if (prev) finish(lo3[0], lo3[1], hi3[0], hi3[1], acc[3], 3, rb - 1);
             SA_FENCE();
             SA_MFMA(0, 3, acc[0]);
             SA_FENCE();
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
             SA_FENCE();
             SA_MFMA(2, 1, acc[2]);
             SA_FENCE();
-            finish(lo0[0], lo0[1], hi0[0], hi0[1], thr[0], 1u << (rb * QB + 0));
+            finish(lo0[0], lo0[1], hi0[0], hi0[1], acc[0], 0, rb);
             SA_FENCE();
             SA_MFMA(2, 2, acc[2]);
             SA_FENCE();
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
             SA_FENCE();
             SA_MFMA(3, 1, acc[3]);
             SA_FENCE();
-            finish(lo1[0], lo1[1], hi1[0], hi1[1], thr[1], 1u << (rb * QB + 1));
+            finish(lo1[0], lo1[1], hi1[0], hi1[1], acc[1], 1, rb);
             SA_FENCE();
             SA_MFMA(3, 2, acc[3]);
             SA_FENCE();
@@ -304,47 +325,13 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
                 for (int ks = 0; ks < 4; ks++) af[ks] = afn[ks];
             }
         }
-        finish(lo2[0], lo2[1], hi2[0], hi2[1], thr[2], 1u << ((NB - 1) * QB + 2));
+        finish(lo2[0], lo2[1], hi2[0], hi2[1], acc[2], 2, NB - 1);
         half_min(acc[3], 0, lo3[0], lo3[1]);
         half_min(acc[3], 8, hi3[0], hi3[1]);
-        finish(lo3[0], lo3[1], hi3[0], hi3[1], thr[3], 1u << ((NB - 1) * QB + 3));
+        finish(lo3[0], lo3[1], hi3[0], hi3[1], acc[3], 3, NB - 1);
         SA_FENCE();
 #undef SA_MFMA
 #undef SA_FENCE
-        if (hits) {
-#pragma unroll 1
-            for (int rb = 0; rb < TT / 32; rb++) {
-                if (!((hits >> (rb * QB)) & ((1u << QB) - 1u))) continue;
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) load_af(rb, ks, af[ks]);
-#pragma unroll
-                for (int g = 0; g < 4; g++) load_bias(rb, g, cinit);
-                const int idx0 = tile * TT + rb * 32 + 4 * h;
-#pragma unroll
-                for (int qb = 0; qb < QB; qb++) {
-                    if (!((hits >> (rb * QB + qb)) & 1u)) continue;
-                    v16i again = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[qb][0], cinit, 0, 0, 0);
-#pragma unroll
-                    for (int ks = 1; ks < 4; ks++)
-                        again = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bf[qb][ks], again, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int sv = again[r];
-                        // most rows lose against the running second-best in every lane: skip them whole
-                        if (__any(sv < thr[qb])) {
-                            const int idx = idx0 + (r & 3) + 8 * (r >> 2);
-                            if (sv < b1[qb]) {
-                                b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = sv; i1[qb] = idx;
-                            } else if (sv < b2[qb]) {
-                                b2[qb] = sv; i2[qb] = idx;
-                            }
-                        }
-                    }
-                    const int p1 = __shfl_xor(b1[qb], 32), p2 = __shfl_xor(b2[qb], 32);
-                    thr[qb] = min(max(b1[qb], p1), min(b2[qb], p2));
-                }
-            }
-        }
         if (tile + 1 < tile_end) commit(buf ^ 1);
         __syncthreads();
     }
