@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,20 @@ int fail(int code, const std::string &msg);
 
 // Grow-only device buffer: frees and reallocates when `want` exceeds `*have`.
 int ensure_bytes(void **buf, size_t *have, size_t want);
+
+// True when some byte of [p, p + n) has its top bit set (a descriptor value above 127): eight bytes per step.
+inline bool any_byte_above_127(const uint8_t *p, size_t n) {
+    size_t i = 0;
+    uint64_t acc = 0;
+    for (; i < n && (reinterpret_cast<uintptr_t>(p + i) & 7); i++) acc |= p[i];
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        acc |= w;
+    }
+    for (; i < n; i++) acc |= p[i];
+    return (acc & 0x8080808080808080ull) != 0;
+}
 
 }  // namespace sa
 

@@ -348,8 +348,10 @@ int sift_extract_batch_u8(sift_group *g, const uint8_t *frames, int n, int w, in
         if (e) {
             rc[r] = e;
             msg[r] = sift_last_error();  // this thread's message
-            hipSetDevice(g->ctx[r]->device);
+            hipSetDevice(g->ctx[r]->device);  // nothing of this GPU's pipeline is left in flight
+            if (g->pipe[r].up) hipStreamSynchronize(g->pipe[r].up);
             hipStreamSynchronize(g->ctx[r]->stream);
+            if (g->pipe[r].down) hipStreamSynchronize(g->pipe[r].down);
         }
     };
     if (ngpu == 1) {
@@ -371,10 +373,8 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
     if (!g || (nq > 0 && (!q || !out)) || (nt > 0 && !t)) return fail(SIFT_ERR_INVALID, "NULL argument");
     if (nq < 0 || nt < 0) return fail(SIFT_ERR_INVALID, "negative count");
     if (nq == 0) return SIFT_OK;
-    for (size_t i = 0; i < (size_t)nq * 128; i++)
-        if (q[i] > 127) return fail(SIFT_ERR_NOT_INTEGRAL, "query descriptor value above 127");
-    for (size_t i = 0; i < (size_t)nt * 128; i++)
-        if (t[i] > 127) return fail(SIFT_ERR_NOT_INTEGRAL, "train descriptor value above 127");
+    if (any_byte_above_127(q, (size_t)nq * 128)) return fail(SIFT_ERR_NOT_INTEGRAL, "query descriptor value above 127");
+    if (any_byte_above_127(t, (size_t)nt * 128)) return fail(SIFT_ERR_NOT_INTEGRAL, "train descriptor value above 127");
     const int ngpu = (int)g->ctx.size();
     // one communicator rank per GPU: members that share a GPU can split frames between them, not a train set
     for (int i = 0; i < ngpu; i++)
@@ -393,6 +393,18 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
             return fail(SIFT_ERR_HIP, std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(e));
         }
     }
+    // Whatever fails below, no stream of the group is left with work that still reads the caller's buffers.
+    struct Drain {
+        sift_group *g;
+        bool armed = true;
+        ~Drain() {
+            if (!armed) return;
+            for (sift_ctx *c : g->ctx) {
+                hipSetDevice(c->device);
+                hipStreamSynchronize(c->stream);
+            }
+        }
+    } drain{g};
     std::vector<int64_t> bounds((size_t)ngpu + 1);
     sift_shard_bounds(nt, ngpu, bounds.data());
     int32_t slice = 0, lo = 0, hi = 0;
@@ -458,6 +470,7 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
         HIP_TRY(hipSetDevice(g->ctx[r]->device));
         HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream));
     }
+    drain.armed = false;
     return SIFT_OK;
 }
 

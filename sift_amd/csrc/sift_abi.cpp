@@ -854,10 +854,8 @@ int sift_knn2_u8(sift_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int 
     if (!ctx || (nq > 0 && (!q || !out)) || (nt > 0 && !t)) return fail(SIFT_ERR_INVALID, "NULL argument");
     if (nq < 0 || nt < 0) return fail(SIFT_ERR_INVALID, "negative count");
     if (nq == 0) return SIFT_OK;
-    for (size_t i = 0; i < (size_t)nq * 128; i++)
-        if (q[i] > 127) return fail(SIFT_ERR_NOT_INTEGRAL, "query descriptor value above 127");
-    for (size_t i = 0; i < (size_t)nt * 128; i++)
-        if (t[i] > 127) return fail(SIFT_ERR_NOT_INTEGRAL, "train descriptor value above 127");
+    if (any_byte_above_127(q, (size_t)nq * 128)) return fail(SIFT_ERR_NOT_INTEGRAL, "query descriptor value above 127");
+    if (any_byte_above_127(t, (size_t)nt * 128)) return fail(SIFT_ERR_NOT_INTEGRAL, "train descriptor value above 127");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t qb = ((size_t)nq * 128 + 255) & ~(size_t)255, tb = ((size_t)nt * 128 + 255) & ~(size_t)255;
     const size_t ob = ((size_t)nq * sizeof(sift_knn2) + 255) & ~(size_t)255;
