@@ -53,9 +53,9 @@ struct sift_ctx {
     size_t h_work_bytes = 0;
     void *st_work = nullptr;  // device workspace of the composition calls
     size_t st_work_bytes = 0;
-    hipStream_t aux = nullptr;              // second stream of the small-workload schedule (run_pipeline)
+    hipStream_t aux = nullptr, aux2 = nullptr;   // side streams of the small-workload schedule (run_pipeline): even, odd octaves
     hipEvent_t oct_ready[sa::MAX_OCTAVES] = {};  // level 3 of octave o is complete
-    hipEvent_t aux_done = nullptr;
+    hipEvent_t aux_done = nullptr, aux2_done = nullptr;
     hipEvent_t group_ev[5] = {};  // timing events at the reference's stage boundaries (run_pipeline's `group_ms`)
     void *pinned = nullptr;  // page-locked host staging of the single-image calls and of result downloads
     size_t pinned_bytes = 0;

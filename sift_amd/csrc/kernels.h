@@ -11,11 +11,23 @@ int pyramid_init_attributes();
 void launch_base(hipStream_t st, const uint8_t *frames, int W, int H, int nframes, const Pyramid &p, const Taps &taps,
                  int ntaps);
 void launch_blur(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &taps, int ntaps);
+// Octaves of at most this many pixels are blurred, all levels and all such octaves, by one launch with a workgroup
+// per frame (two planes and a quarter in LDS).
+constexpr int SMALL_OCTAVE_PIXELS = 8192;
+// First octave from which on every octave is that small (p.octaves if none is).
+int first_small_octave(const Pyramid &p);
+// Levels 1..5 of the octaves o_first.. of every frame; level 0 of octave o_first must be in place.  False (and no
+// launch) if the tap counts are not the five the kernel is compiled for.
+bool launch_small_octaves(hipStream_t st, const Pyramid &p, int o_first, int nframes, const Taps *lvl_taps,
+                          const int *lvl_ntaps);
 void launch_bgr_to_gray(hipStream_t st, const uint8_t *bgr, uint8_t *gray, size_t npix);
 
 // kernels_extrema.hip
 void launch_extrema_gradients(hipStream_t st, const Pyramid &p, int oct, int nframes, Candidate *cand, int cand_cap,
                               FrameCounters *counters);
+// The same for every octave from oct_first on, in one launch (for octaves of a tile or two each).
+void launch_extrema_gradients_from(hipStream_t st, const Pyramid &p, int oct_first, int nframes, Candidate *cand,
+                                   int cand_cap, FrameCounters *counters);
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
                             DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
                             int32_t *n_localized);
@@ -25,8 +37,10 @@ void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevK
                   uint8_t *flags, int kp_cap, FrameCounters *counters);
 
 // kernels_descriptor.hip
+int descriptor_init_attributes();
+// `few_keypoints`: the launch is one or a few frames; keypoints get eight waves each instead of two.
 void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
-                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc);
+                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc, bool few_keypoints);
 
 // Per frame {contributing samples, LDS atomics} of the descriptor stage for the keypoints of the last run (`cursors` and
 // `work` must be zero on entry).

@@ -29,12 +29,13 @@ namespace {
 
 constexpr int DBINS = 8;
 constexpr int INNER = WINDOW_WIDTH * WINDOW_WIDTH * DBINS;  // 128
-constexpr int NWAVES = 2;
+// Waves per keypoint: two when the launch has keypoints enough to fill the chip (more waves per workgroup cost
+// throughput: 16.1 ms against 14.6 per 64 frames with four); eight for a launch of one or a few frames, where the time
+// of the stage is the time of its largest windows.  The copies are summed in one fixed order either way, but the
+// two orders differ, so a sum may differ in its last bits between the two.
+constexpr int NWAVES_BATCH = 2, NWAVES_FEW = 8;
 constexpr int COPIES_PER_WAVE = 8;
-constexpr int NT = NWAVES * 64;  // threads per workgroup
-static_assert(NT >= INNER, "one thread per bin in the normalisation");
 constexpr int ROWS_IN_FLIGHT = 4;
-constexpr int NCOPY = NWAVES * COPIES_PER_WAVE;
 constexpr int RS = WINDOW_WIDTH * DBINS, CS = DBINS;  // doubles between cell rows / cell columns of a tensor copy
 // Copies start two LDS bank pairs apart: equal bins of different copies then lie in different banks, and so do bins
 // that differ by one orientation step (the commonest difference between neighbouring pixels).  Measured per 64 1080p
@@ -60,9 +61,10 @@ __device__ __forceinline__ double lane_broadcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+template <int NWAVES>
 struct DescShared {
     double wtab[256];
-    double tensor[NCOPY][CSTRIDE];  // after the copies are summed, its first 2*INNER doubles hold the sums and their squares
+    double tensor[NWAVES * COPIES_PER_WAVE][CSTRIDE];  // after the copies are summed, its first 2*INNER doubles hold the sums and their squares
     int idx;
 };
 
@@ -70,12 +72,15 @@ struct DescShared {
 // scattering them, counts them: per frame the samples that contribute (non-zero gradient inside the rotated window)
 // and the LDS double atomics they would issue (two per cell corner that lies inside the 4x4 grid), into
 // work[frame][0..1].  It exists so that the kernel's throughput can be stated in the unit that bounds it.
-template <bool COUNT>
-__global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
+template <bool COUNT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
                                                       const FrameCounters *__restrict__ counters,
                                                       int32_t *__restrict__ cursors, uint8_t *__restrict__ desc,
                                                       unsigned long long *__restrict__ work) {
-    __shared__ DescShared sm;
+    constexpr int NT = NWAVES * 64, NCOPY = NWAVES * COPIES_PER_WAVE;
+    static_assert(NT >= INNER, "one thread per bin in the normalisation");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // 67 KB with eight waves: beyond the static limit
+    DescShared<NWAVES> &sm = *reinterpret_cast<DescShared<NWAVES> *>(dyn_lds);
     const int f = blockIdx.y;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -305,17 +310,30 @@ __global__ __launch_bounds__(NT) void k_descriptors(Pyramid p, const DevKeypoint
 
 }  // namespace
 
+int descriptor_init_attributes() {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_descriptors<false, NWAVES_FEW>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DescShared<NWAVES_FEW>));
+    return e == hipSuccess ? 0 : -1;
+}
+
 void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
-                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc) {
-    dim3 grid(2048 / NWAVES, nframes);
-    hipLaunchKernelGGL(k_descriptors<false>, grid, dim3(NT), 0, st, p, kps, kp_cap, counters, cursors, desc,
-                       (unsigned long long *)nullptr);
+                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc, bool few_keypoints) {
+    if (few_keypoints) {
+        dim3 grid(512, nframes);  // two workgroups per CU
+        hipLaunchKernelGGL((k_descriptors<false, NWAVES_FEW>), grid, dim3(NWAVES_FEW * 64), sizeof(DescShared<NWAVES_FEW>), st, p, kps, kp_cap, counters,
+                           cursors, desc, (unsigned long long *)nullptr);
+    } else {
+        dim3 grid(2048 / NWAVES_BATCH, nframes);
+        hipLaunchKernelGGL((k_descriptors<false, NWAVES_BATCH>), grid, dim3(NWAVES_BATCH * 64), sizeof(DescShared<NWAVES_BATCH>), st, p, kps, kp_cap, counters,
+                           cursors, desc, (unsigned long long *)nullptr);
+    }
 }
 
 void launch_descriptor_work(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
                             const FrameCounters *counters, int32_t *cursors, unsigned long long *work) {
-    dim3 grid(2048 / NWAVES, nframes);
-    hipLaunchKernelGGL(k_descriptors<true>, grid, dim3(NT), 0, st, p, kps, kp_cap, counters, cursors, (uint8_t *)nullptr, work);
+    dim3 grid(2048 / NWAVES_BATCH, nframes);
+    hipLaunchKernelGGL((k_descriptors<true, NWAVES_BATCH>), grid, dim3(NWAVES_BATCH * 64), sizeof(DescShared<NWAVES_BATCH>), st, p, kps, kp_cap, counters,
+                       cursors, (uint8_t *)nullptr, work);
 }
 
 }  // namespace sa

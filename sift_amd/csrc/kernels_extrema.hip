@@ -108,13 +108,10 @@ __device__ __forceinline__ double min_finite(double a, double b) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_extrema_grad(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
-                                                       FrameCounters *__restrict__ counters) {
-    __shared__ double knots[33][2];
-    if (threadIdx.x < 66) (&knots[0][0])[threadIdx.x] = (&kAtanKnots[0][0])[threadIdx.x];
-    __syncthreads();
+__device__ __forceinline__ void extrema_grad_tile(const Pyramid &p, int oct, const TileId tile,
+                                                  Candidate *__restrict__ cand, int cand_cap,
+                                                  FrameCounters *__restrict__ counters, const double (*knots)[2]) {
     const int w = p.w[oct], h = p.h[oct];
-    const TileId tile = xcd_tile_id();
     const int f = tile.z;
     const size_t plane = (size_t)w * h;
     const double *G = p.gauss[oct] + (size_t)f * IMAGES * plane;
@@ -205,6 +202,38 @@ __global__ __launch_bounds__(256) void k_extrema_grad(Pyramid p, int oct, Candid
                 }
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_extrema_grad(Pyramid p, int oct, Candidate *__restrict__ cand, int cand_cap,
+                                                       FrameCounters *__restrict__ counters) {
+    __shared__ double knots[33][2];
+    if (threadIdx.x < 66) (&knots[0][0])[threadIdx.x] = (&kAtanKnots[0][0])[threadIdx.x];
+    __syncthreads();
+    extrema_grad_tile(p, oct, xcd_tile_id(), cand, cand_cap, counters, knots);
+}
+
+// The same for several small octaves in one launch (a single frame's upper octaves are one or two tiles each):
+// blockIdx.x runs through the tiles of octaves oct_first.. in turn, blockIdx.y is the frame.
+__global__ __launch_bounds__(256) void k_extrema_grad_octaves(Pyramid p, int oct_first, Candidate *__restrict__ cand,
+                                                               int cand_cap, FrameCounters *__restrict__ counters) {
+    __shared__ double knots[33][2];
+    if (threadIdx.x < 66) (&knots[0][0])[threadIdx.x] = (&kAtanKnots[0][0])[threadIdx.x];
+    __syncthreads();
+    int t = blockIdx.x;
+    for (int oct = oct_first; oct < p.octaves; oct++) {
+        const int w = p.w[oct], h = p.h[oct];
+        if (w <= 2 * BORDER || h <= 2 * BORDER || !p.grad[oct]) continue;  // nothing is scanned here (sift.cpp:188, :233)
+        const int nx = (w + EX_TW - 1) / EX_TW, ny = (h + EX_TH - 1) / EX_TH;
+        if (t < nx * ny) {
+            TileId tile;
+            tile.x = t % nx;
+            tile.y = t / nx;
+            tile.z = blockIdx.y;
+            extrema_grad_tile(p, oct, tile, cand, cand_cap, counters, knots);
+            return;
+        }
+        t -= nx * ny;
     }
 }
 
@@ -535,6 +564,18 @@ void launch_extrema_gradients(hipStream_t st, const Pyramid &p, int oct, int nfr
     if (w <= 2 * BORDER || h <= 2 * BORDER || !p.grad[oct]) return;
     dim3 grid((w + EX_TW - 1) / EX_TW, (h + EX_TH - 1) / EX_TH, nframes);
     hipLaunchKernelGGL(k_extrema_grad, grid, dim3(256), 0, st, p, oct, cand, cand_cap, counters);
+}
+
+void launch_extrema_gradients_from(hipStream_t st, const Pyramid &p, int oct_first, int nframes, Candidate *cand,
+                                   int cand_cap, FrameCounters *counters) {
+    int tiles = 0;
+    for (int oct = oct_first; oct < p.octaves; oct++) {
+        const int w = p.w[oct], h = p.h[oct];
+        if (w <= 2 * BORDER || h <= 2 * BORDER || !p.grad[oct]) continue;
+        tiles += ((w + EX_TW - 1) / EX_TW) * ((h + EX_TH - 1) / EX_TH);
+    }
+    if (tiles == 0) return;
+    hipLaunchKernelGGL(k_extrema_grad_octaves, dim3(tiles, nframes), dim3(256), 0, st, p, oct_first, cand, cand_cap, counters);
 }
 
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,

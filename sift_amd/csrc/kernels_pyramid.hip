@@ -387,7 +387,9 @@ void strip_grid(int w, int h, int nframes, dim3 &grid, int &strip_h) {
     constexpr int TW = MarchGeom<R>::TW, MCH = MarchGeom<R>::MCH;
     const int nx = (w + TW - 1) / TW;
     int ny = (2048 + nx * nframes - 1) / (nx * nframes);
-    const int max_ny = (h + 127) / 128;  // at least 128 rows per strip
+    // At least 32 rows per strip.  Short strips repeat their 2R halo rows, which only a launch that cannot fill
+    // the chip anyway (a single frame) gets to: there the shorter walk of each workgroup is the latency of the level.
+    const int max_ny = (h + 31) / 32;
     if (ny > max_ny) ny = max_ny;
     if (ny < 1) ny = 1;
     strip_h = (h + ny - 1) / ny;
@@ -429,6 +431,108 @@ __global__ void k_bgr_to_gray(const uint8_t *__restrict__ bgr, uint8_t *__restri
     }
 }
 
+// ---- every blur level of the small octaves in one launch ----
+//
+// An octave of a few thousand pixels does not fill one CU, and its five blur launches cost their launch latency
+// five times over; a single frame spends a third of its time on the 15-20 such launches of its upper octaves.
+// Here one workgroup per frame holds the octave in LDS and walks through the five levels and on through every
+// following octave: level j is the row pass of level j-1 into a scratch plane, then the column pass back (the
+// same operation order as march(): taps left to right in the row pass, centre tap first and then the pairs
+// outwards in the column pass, borders reflected), each level written to the pyramid as it is finished and the
+// even pixels of level 3 kept as the next octave's level 0 (sift.cpp:154-158).
+constexpr int SMALL_NT = 1024;
+
+struct SmallTaps {
+    Taps lvl[IMAGES];  // [1..IMAGES-1] are used
+};
+
+constexpr int SMALL_RMAX = 13;  // widest filter: the reflection tables reach this far past either border
+
+// rx[i] = reflect101(i - SMALL_RMAX, w) and ry likewise for h: the filters index them instead of reflecting.
+template <int R>
+__device__ __forceinline__ void small_level(double *A, double *T, const int *rx, const int *ry, int w, int h,
+                                            const Taps &taps, double *__restrict__ out, double *__restrict__ nxt,
+                                            double *N, int nw, int nh) {
+    const int n = w * h;
+    // Indices first, then every operand, then the sum: the reads of a pixel are all in flight together instead of
+    // each waiting for its table entry in turn.
+    for (int p = threadIdx.x; p < n; p += SMALL_NT) {
+        const int y = p / w, x = p - y * w;
+        const double *row = A + y * w;
+        const int *cx = rx + x + (SMALL_RMAX - R);  // cx[t] = reflect101(x - R + t, w)
+        int at[2 * R + 1];
+        double v[2 * R + 1];
+#pragma unroll
+        for (int t = 0; t <= 2 * R; t++) at[t] = cx[t];
+#pragma unroll
+        for (int t = 0; t <= 2 * R; t++) v[t] = row[at[t]];
+        double acc = taps.c[0] * v[0];
+#pragma unroll
+        for (int t = 1; t <= 2 * R; t++) acc += taps.c[t] * v[t];
+        T[p] = acc;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += SMALL_NT) {
+        const int y = p / w, x = p - y * w;
+        const int *cy = ry + y + (SMALL_RMAX - R);  // cy[t] = reflect101(y - R + t, h)
+        int at[2 * R + 1];
+        double v[2 * R + 1];
+#pragma unroll
+        for (int t = 0; t <= 2 * R; t++) at[t] = cy[t];
+#pragma unroll
+        for (int t = 0; t <= 2 * R; t++) v[t] = T[at[t] * w + x];
+        double acc = taps.c[R] * v[R];
+#pragma unroll
+        for (int t = 1; t <= R; t++) acc += taps.c[R + t] * (v[R + t] + v[R - t]);
+        A[p] = acc;  // the previous level is dead: the row pass has consumed it
+        out[p] = acc;
+        if (nxt && !(y & 1) && !(x & 1) && (y >> 1) < nh && (x >> 1) < nw) {
+            nxt[(y >> 1) * nw + (x >> 1)] = acc;
+            N[(y >> 1) * nw + (x >> 1)] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+// grid: frames.  LDS: two planes of the first octave taken, one of the octave after it (that octave's level 0)
+// and the two reflection tables.
+__global__ __launch_bounds__(SMALL_NT) void k_small_octaves(Pyramid p, int o_first, SmallTaps taps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const size_t f = blockIdx.x;
+    const int cap = p.w[o_first] * p.h[o_first];
+    const int next_cap = o_first + 1 < p.octaves ? p.w[o_first + 1] * p.h[o_first + 1] : 0;
+    double *A = smem, *T = smem + cap, *N = smem + 2 * cap;
+    int *rx = reinterpret_cast<int *>(N + next_cap);
+    int *ry = rx + p.w[o_first] + 2 * SMALL_RMAX;
+    for (int o = o_first; o < p.octaves; o++) {
+        const int w = p.w[o], h = p.h[o], n = w * h;
+        double *G = p.gauss[o] + f * IMAGES * (size_t)n;
+        if (o == o_first) {
+            for (int i = threadIdx.x; i < n; i += SMALL_NT) A[i] = G[i];
+        } else {
+            for (int i = threadIdx.x; i < n; i += SMALL_NT) A[i] = N[i];
+        }
+        for (int i = threadIdx.x; i < w + 2 * SMALL_RMAX; i += SMALL_NT) rx[i] = reflect101(i - SMALL_RMAX, w);
+        for (int i = threadIdx.x; i < h + 2 * SMALL_RMAX; i += SMALL_NT) ry[i] = reflect101(i - SMALL_RMAX, h);
+        __syncthreads();
+        double *nxt = nullptr;
+        int nw = 0, nh = 0;
+        if (o + 1 < p.octaves) {
+            nw = p.w[o + 1];
+            nh = p.h[o + 1];
+            nxt = p.gauss[o + 1] + f * IMAGES * (size_t)nw * nh;
+        }
+        static_assert(IMAGES == 6, "five blur levels of fixed radii");
+        small_level<5>(A, T, rx, ry, w, h, taps.lvl[1], G + (size_t)1 * n, nullptr, N, 0, 0);
+        small_level<6>(A, T, rx, ry, w, h, taps.lvl[2], G + (size_t)2 * n, nullptr, N, 0, 0);
+        small_level<8>(A, T, rx, ry, w, h, taps.lvl[3], G + (size_t)3 * n, nxt, N, nw, nh);
+        small_level<10>(A, T, rx, ry, w, h, taps.lvl[4], G + (size_t)4 * n, nullptr, N, 0, 0);
+        small_level<13>(A, T, rx, ry, w, h, taps.lvl[5], G + (size_t)5 * n, nullptr, N, 0, 0);
+    }
+}
+
+constexpr size_t SMALL_LDS_MAX = 160 * 1024;
+
 template <int R>
 int set_lds_attr() {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blur_march<R>),
@@ -447,6 +551,9 @@ int pyramid_init_attributes() {
     rc |= set_lds_attr<13>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_base_march<5>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MarchGeom<5>::LDS_BYTES);
+    if (e != hipSuccess) rc = -1;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small_octaves), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)SMALL_LDS_MAX);
     if (e != hipSuccess) rc = -1;
     return rc;
 }
@@ -480,6 +587,31 @@ void launch_blur(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes
         case 13: launch_blur_r<13>(st, p, oct, lvl, nframes, taps); break;
         default: break;  // rejected on the host before any launch
     }
+}
+
+int first_small_octave(const Pyramid &p) {
+    int o = p.octaves;
+    while (o > 0 && p.w[o - 1] * p.h[o - 1] <= SMALL_OCTAVE_PIXELS) o--;
+    return o;
+}
+
+bool launch_small_octaves(hipStream_t st, const Pyramid &p, int o_first, int nframes, const Taps *lvl_taps,
+                          const int *lvl_ntaps) {
+    if (o_first >= p.octaves) return true;
+    const int radii[IMAGES] = {0, 5, 6, 8, 10, 13};
+    SmallTaps taps;
+    for (int l = 1; l < IMAGES; l++) {
+        if (lvl_ntaps[l] != 2 * radii[l] + 1) return false;
+        taps.lvl[l] = lvl_taps[l];
+    }
+    taps.lvl[0] = lvl_taps[1];  // unused
+    const int cap = p.w[o_first] * p.h[o_first];
+    const int next = o_first + 1 < p.octaves ? p.w[o_first + 1] * p.h[o_first + 1] : 0;  // octaves only shrink
+    const size_t lds = ((size_t)2 * cap + next) * sizeof(double) +
+                       (size_t)(p.w[o_first] + p.h[o_first] + 4 * SMALL_RMAX) * sizeof(int);  // planes, reflection tables
+    if (cap > SMALL_OCTAVE_PIXELS || lds > SMALL_LDS_MAX) return false;
+    hipLaunchKernelGGL(k_small_octaves, dim3(nframes), dim3(SMALL_NT), lds, st, p, o_first, taps);
+    return true;
 }
 
 }  // namespace sa

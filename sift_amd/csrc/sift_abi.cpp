@@ -114,7 +114,7 @@ int sift_ctx_create(int device, sift_ctx **out) {
         delete c;
         return fail(SIFT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    if (pyramid_init_attributes() != 0) {
+    if (pyramid_init_attributes() != 0 || descriptor_init_attributes() != 0) {
         hipStreamDestroy(c->stream);
         delete c;
         return fail(SIFT_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -141,9 +141,11 @@ int sift_ctx_destroy(sift_ctx *ctx) {
     if (ctx->st_work) hipFree(ctx->st_work);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->aux) hipStreamDestroy(ctx->aux);
+    if (ctx->aux2) hipStreamDestroy(ctx->aux2);
     for (hipEvent_t e : ctx->oct_ready)
         if (e) hipEventDestroy(e);
     if (ctx->aux_done) hipEventDestroy(ctx->aux_done);
+    if (ctx->aux2_done) hipEventDestroy(ctx->aux2_done);
     for (hipEvent_t e : ctx->group_ev)
         if (e) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -366,25 +368,30 @@ struct StageTimer {
 
 }  // namespace
 
-// Second stream and its events, created together: the context keeps them only if every creation succeeded.
+// Side streams and their events, created together: the context keeps them only if every creation succeeded.
 static int ensure_aux(sift_ctx *ctx) {
     if (ctx->aux) return SIFT_OK;
-    hipStream_t aux = nullptr;
+    hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ready[MAX_OCTAVES] = {};
-    hipEvent_t done = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking);
     for (int i = 0; i < MAX_OCTAVES && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         for (hipEvent_t ev : ready)
             if (ev) hipEventDestroy(ev);
-        if (done) hipEventDestroy(done);
-        if (aux) hipStreamDestroy(aux);
-        return fail(SIFT_ERR_HIP, std::string("second stream set-up: ") + hipGetErrorString(e));
+        for (int i = 0; i < 2; i++) {
+            if (done[i]) hipEventDestroy(done[i]);
+            if (aux[i]) hipStreamDestroy(aux[i]);
+        }
+        return fail(SIFT_ERR_HIP, std::string("side stream set-up: ") + hipGetErrorString(e));
     }
     for (int i = 0; i < MAX_OCTAVES; i++) ctx->oct_ready[i] = ready[i];
-    ctx->aux_done = done;
-    ctx->aux = aux;
+    ctx->aux_done = done[0];
+    ctx->aux2_done = done[1];
+    ctx->aux2 = aux[1];
+    ctx->aux = aux[0];
     return SIFT_OK;
 }
 
@@ -428,24 +435,45 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_e
     if (two_streams) {
         int rc = ensure_aux(ctx);
         if (rc) return rc;
-        hipStream_t aux = ctx->aux;
-        // Once the second stream has work, every way out of this block joins it first: later calls on the main
+        hipStream_t side[2] = {ctx->aux, ctx->aux2};
+        // Once a side stream has work, every way out of this block joins both first: later calls on the main
         // stream must not overlap kernels that are still writing the pyramid and the candidate lists.
         hipError_t e = hipSuccess;
         launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps);
+        // The upper octaves are a few thousand pixels each: all their levels are one launch on the main stream
+        // (behind level 3 of the last large octave, which writes their first level 0), followed by their scans.
+        // The main stream's launches are all enqueued before the second stream's: the host needs longer to
+        // enqueue a small launch than the GPU to run it, and the chain that everything waits for is the main one.
+        int o_small = first_small_octave(b->pyr), o_large = b->pyr.octaves;
         for (int o = 0; o < b->pyr.octaves && e == hipSuccess; o++) {
+            if (o == o_small) {
+                if (launch_small_octaves(st, b->pyr, o_small, n, b->lvl_taps, b->lvl_ntaps)) {
+                    launch_extrema_gradients_from(st, b->pyr, o_small, n, b->d_cand, b->cand_cap, b->d_counters);
+                    o_large = o_small;
+                    break;
+                }
+                o_small = b->pyr.octaves;  // not taken: these octaves go level by level like the others
+            }
             for (int lvl = 1; lvl <= IMAGES - 3; lvl++) launch_blur(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
-            if ((e = hipEventRecord(ctx->oct_ready[o], st)) != hipSuccess) break;
+            e = hipEventRecord(ctx->oct_ready[o], st);
+        }
+        // levels 4-5 and the scan of an octave depend on nothing of the other octaves: even and odd octaves take turns
+        // on the two side streams
+        for (int o = 0; o < o_large && e == hipSuccess; o++) {
+            hipStream_t aux = side[o & 1];
             if ((e = hipStreamWaitEvent(aux, ctx->oct_ready[o], 0)) != hipSuccess) break;
             for (int lvl = IMAGES - 2; lvl < IMAGES; lvl++) launch_blur(aux, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]);
             launch_extrema_gradients(aux, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters);
         }
         if (e == hipSuccess && group_events) e = hipEventRecord(ctx->group_ev[1], st);
-        if (e == hipSuccess) e = hipEventRecord(ctx->aux_done, aux);
+        if (e == hipSuccess) e = hipEventRecord(ctx->aux_done, side[0]);
+        if (e == hipSuccess) e = hipEventRecord(ctx->aux2_done, side[1]);
         if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->aux_done, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->aux2_done, 0);
         if (e != hipSuccess) {
-            hipStreamSynchronize(aux);
-            return fail(SIFT_ERR_HIP, std::string("two-stream schedule: ") + hipGetErrorString(e));
+            hipStreamSynchronize(side[0]);
+            hipStreamSynchronize(side[1]);
+            return fail(SIFT_ERR_HIP, std::string("side-stream schedule: ") + hipGetErrorString(e));
         }
     } else {
         TIMED(SIFT_STAGE_BASE, launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
@@ -464,7 +492,7 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_e
           launch_clean(st, n, b->d_oriented, b->d_sorted, b->d_final, b->d_flags, b->kp_cap, b->d_counters));
     if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[3], st));
     TIMED(SIFT_STAGE_DESCRIPTOR, launch_descriptors(st, b->pyr, n, b->d_final, b->kp_cap, b->d_counters,
-                                                    b->d_cursors + b->max_frames, b->d_desc));
+                                                    b->d_cursors + b->max_frames, b->d_desc, two_streams));
     if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[4], st));
 #undef TIMED
     HIP_TRY(hipGetLastError());
