@@ -28,19 +28,23 @@ void launch_extrema_gradients(hipStream_t st, const Pyramid &p, int oct, int nfr
 // The same for every octave from oct_first on, in one launch (for octaves of a tile or two each).
 void launch_extrema_gradients_from(hipStream_t st, const Pyramid &p, int oct_first, int nframes, Candidate *cand,
                                    int cand_cap, FrameCounters *counters);
+// `few_keypoints`: one or a few frames; the orientation windows get a workgroup each instead of a wave.
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
                             DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
-                            int32_t *n_localized);
+                            int32_t *n_localized, bool few_keypoints);
 
 // kernels_keypoints.hip
+// `ranks` ([nframes][kp_cap] of scratch, or null): when given, the rank sort is spread over eight times as many
+// workgroups (for launches of one or a few frames).
 void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevKeypoint *sorted, DevKeypoint *final_kp,
-                  uint8_t *flags, int kp_cap, FrameCounters *counters);
+                  uint8_t *flags, int kp_cap, FrameCounters *counters, int32_t *ranks);
 
 // kernels_descriptor.hip
 int descriptor_init_attributes();
-// `few_keypoints`: the launch is one or a few frames; keypoints get eight waves each instead of two.
+// `launch_pixels` = frames x width x height of the launch: up to 1 M pixels keypoints get eight waves each, up to 4 M
+// four, beyond that two.
 void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
-                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc, bool few_keypoints);
+                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc, int64_t launch_pixels);
 
 // Per frame {contributing samples, LDS atomics} of the descriptor stage for the keypoints of the last run (`cursors` and
 // `work` must be zero on entry).

@@ -30,10 +30,11 @@ namespace {
 constexpr int DBINS = 8;
 constexpr int INNER = WINDOW_WIDTH * WINDOW_WIDTH * DBINS;  // 128
 // Waves per keypoint: two when the launch has keypoints enough to fill the chip (more waves per workgroup cost
-// throughput: 16.1 ms against 14.6 per 64 frames with four); eight for a launch of one or a few frames, where the time
-// of the stage is the time of its largest windows.  The copies are summed in one fixed order either way, but the
+// throughput: 16.1 ms against 14.6 per 64 frames with four); four or eight for a launch of one or a few frames, where
+// the time of the stage is the time of its largest windows (a 512 x 512 frame: 169 us with two, 92 with four, 75-84
+// with eight; a 1080p frame has keypoints enough for four).  The copies are summed in one fixed order either way, but the
 // two orders differ, so a sum may differ in its last bits between the two.
-constexpr int NWAVES_BATCH = 2, NWAVES_FEW = 8;
+constexpr int NWAVES_BATCH = 2, NWAVES_SOME = 4, NWAVES_FEW = 8;
 constexpr int COPIES_PER_WAVE = 8;
 constexpr int ROWS_IN_FLIGHT = 4;
 constexpr int RS = WINDOW_WIDTH * DBINS, CS = DBINS;  // doubles between cell rows / cell columns of a tensor copy
@@ -316,17 +317,21 @@ int descriptor_init_attributes() {
     return e == hipSuccess ? 0 : -1;
 }
 
+template <int NW>
+static void launch_descriptors_nw(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
+                                  const FrameCounters *counters, int32_t *cursors, uint8_t *desc, int blocks) {
+    hipLaunchKernelGGL((k_descriptors<false, NW>), dim3(blocks, nframes), dim3(NW * 64), sizeof(DescShared<NW>), st, p, kps,
+                       kp_cap, counters, cursors, desc, (unsigned long long *)nullptr);
+}
+
 void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
-                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc, bool few_keypoints) {
-    if (few_keypoints) {
-        dim3 grid(512, nframes);  // two workgroups per CU
-        hipLaunchKernelGGL((k_descriptors<false, NWAVES_FEW>), grid, dim3(NWAVES_FEW * 64), sizeof(DescShared<NWAVES_FEW>), st, p, kps, kp_cap, counters,
-                           cursors, desc, (unsigned long long *)nullptr);
-    } else {
-        dim3 grid(2048 / NWAVES_BATCH, nframes);
-        hipLaunchKernelGGL((k_descriptors<false, NWAVES_BATCH>), grid, dim3(NWAVES_BATCH * 64), sizeof(DescShared<NWAVES_BATCH>), st, p, kps, kp_cap, counters,
-                           cursors, desc, (unsigned long long *)nullptr);
-    }
+                        const FrameCounters *counters, int32_t *cursors, uint8_t *desc, int64_t launch_pixels) {
+    if (launch_pixels <= ((int64_t)1 << 20))
+        launch_descriptors_nw<NWAVES_FEW>(st, p, nframes, kps, kp_cap, counters, cursors, desc, 512);  // two workgroups per CU
+    else if (launch_pixels <= ((int64_t)1 << 22))
+        launch_descriptors_nw<NWAVES_SOME>(st, p, nframes, kps, kp_cap, counters, cursors, desc, 1024);
+    else
+        launch_descriptors_nw<NWAVES_BATCH>(st, p, nframes, kps, kp_cap, counters, cursors, desc, 2048 / NWAVES_BATCH);
 }
 
 void launch_descriptor_work(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,

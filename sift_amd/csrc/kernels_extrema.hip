@@ -431,6 +431,11 @@ constexpr int OWAVES = 4;             // waves (= keypoints in flight) per workg
 constexpr int WTAB = 128;
 constexpr int OSAMP = 4;             // samples per lane per trip of the window loop (2 and 8 measure the same)
 
+// TEAM = false: a wave per keypoint (launches with keypoints enough to keep every wave busy).  TEAM = true: the four
+// waves of a workgroup share a keypoint, each taking every fourth trip through the window with partial histograms
+// of its own, which wave 0 then adds up wave by wave; for one or a few frames, where the stage lasts as long as its
+// largest windows.  The two modes add the same terms in different orders.
+template <bool TEAM>
 __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeypoint *__restrict__ localized,
                                                          int kp_cap, DevKeypoint *__restrict__ oriented,
                                                          FrameCounters *__restrict__ counters,
@@ -441,13 +446,19 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
     __shared__ double s_wtab[OWAVES][WTAB];
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *hist = s_hist[wv], *hsum = s_hsum[wv], *smooth = s_smooth[wv], *wtab = s_wtab[wv];
+    double *hist = s_hist[wv], *hsum = s_hsum[TEAM ? 0 : wv], *smooth = s_smooth[TEAM ? 0 : wv], *wtab = s_wtab[TEAM ? 0 : wv];
     int n = n_localized[f];
     if (n > kp_cap) n = kp_cap;
     // keypoints are dealt to the waves of the frame round-robin: a shared cursor would cost one
     // same-address global atomic per keypoint, which serialises the whole frame
-    const int wave_in_frame = blockIdx.x * OWAVES + wv, waves_per_frame = gridDim.x * OWAVES;
-    for (int idx = wave_in_frame; idx < n; idx += waves_per_frame) {
+    const int first = TEAM ? blockIdx.x : blockIdx.x * OWAVES + wv, stride = TEAM ? gridDim.x : gridDim.x * OWAVES;
+    // wave-level hand-over between the lanes of a wave; in TEAM mode the waves meet at workgroup barriers instead
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (int idx = first; idx < n; idx += stride) {
         const DevKeypoint kpt = localized[(size_t)f * kp_cap + idx];
         const int layer = kpt.pad & 255, oct = kpt.pad >> 8;
         const int w = p.w[oct], h = p.h[oct];
@@ -459,11 +470,14 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
         const double weight_factor = -0.5 / (scale * scale);
         for (int t = lane; t < BINS * OSTRIDE; t += 64) hist[t] = 0.0;
         const bool use_tab = radius < WTAB;
-        if (use_tab)
-            for (int t = lane; t <= radius; t += 64) wtab[t] = exp(weight_factor * (double)(t * t));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (use_tab) {
+            if constexpr (TEAM) {
+                for (int t = threadIdx.x; t <= radius; t += 64 * OWAVES) wtab[t] = exp(weight_factor * (double)(t * t));
+            } else {
+                for (int t = lane; t <= radius; t += 64) wtab[t] = exp(weight_factor * (double)(t * t));
+            }
+        }
+        if constexpr (TEAM) __syncthreads(); else wave_sync();
         const int n1 = 2 * radius + 1;
         const int total = n1 * n1;
         const int copy = lane & (OCOPIES - 1);
@@ -474,7 +488,12 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
         // Four samples per lane per trip.  Gradient loads are unconditional (addresses clamped
         // into the plane) and the weight-table reads come before the first atomic, so all of a
         // trip's reads are in flight together; samples outside the image are discarded.
-        for (int s0 = lane; s0 < total; s0 += 64 * OSAMP) {
+        constexpr int TRIP = 64 * OSAMP;
+        for (int s0 = lane + (TEAM ? wv * TRIP : 0); s0 < total; s0 += TEAM ? TRIP * OWAVES : TRIP) {
+            if constexpr (TEAM) {  // this wave skips the other waves' trips
+                qi = s0 / n1;
+                rj = s0 - qi * n1;
+            }
             Grad g[OSAMP];
             double wgt[OSAMP];
             bool ok[OSAMP];
@@ -503,18 +522,24 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
                 atomicAdd(&hist[index * OSTRIDE + copy], wgt[u] * g[u].mag);  // sift.cpp:417
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (TEAM) __syncthreads(); else wave_sync();
+        if (TEAM && wv != 0) {
+            __syncthreads();  // the one at the end of the trip: wave 0 is done with the histograms and the table
+            continue;
+        }
         if (lane < BINS) {
-            double t = hist[lane * OSTRIDE];
+            double t = 0.0;
 #pragma unroll
-            for (int c = 1; c < OCOPIES; c++) t += hist[lane * OSTRIDE + c];
+            for (int v = 0; v < (TEAM ? OWAVES : 1); v++) {
+                const double *hv = TEAM ? s_hist[v] : hist;
+                double tv = hv[lane * OSTRIDE];
+#pragma unroll
+                for (int c = 1; c < OCOPIES; c++) tv += hv[lane * OSTRIDE + c];
+                t = v == 0 ? tv : t + tv;
+            }
             hsum[lane] = t;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_sync();
         if (lane < BINS) {
             const int i = lane;
             smooth[i] = (6 * hsum[i] + 4 * (hsum[(i + BINS - 1) % BINS] + hsum[(i + 1) % BINS]) +
@@ -549,9 +574,7 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
                 counters[f].overflow = 1;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (TEAM) __syncthreads(); else wave_sync();
     }
 }
 
@@ -580,11 +603,15 @@ void launch_extrema_gradients_from(hipStream_t st, const Pyramid &p, int oct_fir
 
 void launch_localize_orient(hipStream_t st, const Pyramid &p, int nframes, const Candidate *cand, int cand_cap,
                             DevKeypoint *localized, DevKeypoint *oriented, int kp_cap, FrameCounters *counters,
-                            int32_t *n_localized) {
+                            int32_t *n_localized, bool few_keypoints) {
     hipLaunchKernelGGL(k_localize, dim3((cand_cap + 255) / 256, nframes), dim3(256), 0, st, p, cand, cand_cap,
                        localized, kp_cap, counters, n_localized);
-    hipLaunchKernelGGL(k_orient, dim3(1024 / OWAVES, nframes), dim3(64 * OWAVES), 0, st, p, localized, kp_cap,
-                       oriented, counters, n_localized);
+    if (few_keypoints)
+        hipLaunchKernelGGL(k_orient<true>, dim3(1024, nframes), dim3(64 * OWAVES), 0, st, p, localized, kp_cap, oriented,
+                           counters, n_localized);
+    else
+        hipLaunchKernelGGL(k_orient<false>, dim3(1024 / OWAVES, nframes), dim3(64 * OWAVES), 0, st, p, localized, kp_cap,
+                           oriented, counters, n_localized);
 }
 
 }  // namespace sa

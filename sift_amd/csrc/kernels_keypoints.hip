@@ -56,17 +56,32 @@ __device__ __forceinline__ int cmp_key(const SortKey &a, const SortKey &b) {
 // comparison afterwards.
 constexpr int RS_T = 128;  // threads per workgroup = keys per LDS tile
 
+//
+// SPLIT = false: a workgroup ranks its 128 keypoints against the whole list and moves them (grid: tiles x frames).
+// SPLIT = true: grid tiles x parts x frames; a workgroup counts only the part of the list that blockIdx.y selects
+// and adds its count to ranks[frame][i] (zero on entry), and k_rank_scatter moves the keypoints afterwards: for one
+// or a few frames, whose few tiles would otherwise leave most of the chip idle for the length of the list.
+template <bool SPLIT>
 __global__ __launch_bounds__(RS_T) void k_rank_sort(const DevKeypoint *__restrict__ in, DevKeypoint *__restrict__ out,
-                                                     int kp_cap, const FrameCounters *__restrict__ counters) {
+                                                     int kp_cap, const FrameCounters *__restrict__ counters,
+                                                     int32_t *__restrict__ ranks) {
     __shared__ __attribute__((aligned(16))) uint32_t tile_x[RS_T];
     __shared__ SortKey tile[RS_T];
-    const int f = blockIdx.y;
+    const int f = SPLIT ? blockIdx.z : blockIdx.y;
     int n = counters[f].oriented;
     if (n > kp_cap) n = kp_cap;
     const int i0 = blockIdx.x * RS_T;
     if (i0 >= n) return;
     in += (size_t)f * kp_cap;
     out += (size_t)f * kp_cap;
+    // this workgroup's share of the list, in whole tiles
+    int jlo = 0, jhi = n;
+    if (SPLIT) {
+        const int tiles = (n + RS_T - 1) / RS_T, per = (tiles + gridDim.y - 1) / gridDim.y;
+        jlo = min(n, (int)blockIdx.y * per * RS_T);
+        jhi = min(n, ((int)blockIdx.y + 1) * per * RS_T);
+        if (jlo >= jhi) return;
+    }
     const int i = i0 + threadIdx.x;
     DevKeypoint me;
     SortKey mk, nk;
@@ -77,15 +92,15 @@ __global__ __launch_bounds__(RS_T) void k_rank_sort(const DevKeypoint *__restric
     }
     const uint32_t mx = mk.k[0];
     int rank = 0;
-    if ((int)threadIdx.x < n) nk = make_key(in[threadIdx.x]);
-    for (int j0 = 0; j0 < n; j0 += RS_T) {
+    if (jlo + (int)threadIdx.x < jhi) nk = make_key(in[jlo + threadIdx.x]);
+    for (int j0 = jlo; j0 < jhi; j0 += RS_T) {
         tile[threadIdx.x] = nk;
         tile_x[threadIdx.x] = nk.k[0];
         __syncthreads();
         // next tile's key, loaded while this one is scanned
         const int jn = j0 + RS_T + threadIdx.x;
         for (int q = 0; q < 6; q++) nk.k[q] = 0xffffffffu;
-        if (jn < n) nk = make_key(in[jn]);
+        if (jn < jhi) nk = make_key(in[jn]);
         uint32_t eq[RS_T / 32];
 #pragma unroll
         for (int w = 0; w < RS_T / 32; w++) eq[w] = 0;
@@ -105,12 +120,26 @@ __global__ __launch_bounds__(RS_T) void k_rank_sort(const DevKeypoint *__restric
                 m &= m - 1;
                 const int j = j0 + t;
                 const int c = cmp_key(tile[t], mk);
-                rank += j < n && ((c < 0) || (c == 0 && j < i));
+                rank += j < jhi && ((c < 0) || (c == 0 && j < i));
             }
         }
         __syncthreads();
     }
-    if (i < n) out[rank] = me;
+    if (i < n) {
+        if (SPLIT)
+            atomicAdd(&ranks[(size_t)f * kp_cap + i], rank);
+        else
+            out[rank] = me;
+    }
+}
+
+__global__ void k_rank_scatter(const DevKeypoint *__restrict__ in, DevKeypoint *__restrict__ out, int kp_cap,
+                               const FrameCounters *__restrict__ counters, const int32_t *__restrict__ ranks) {
+    const int f = blockIdx.y;
+    int n = counters[f].oriented;
+    if (n > kp_cap) n = kp_cap;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[(size_t)f * kp_cap + ranks[(size_t)f * kp_cap + i]] = in[(size_t)f * kp_cap + i];
 }
 
 // predicate of sift.cpp:214-217: true when J differs from I
@@ -182,9 +211,17 @@ __global__ __launch_bounds__(1024) void k_unique_finalize(const DevKeypoint *__r
 }  // namespace
 
 void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevKeypoint *sorted, DevKeypoint *final_kp,
-                  uint8_t *flags, int kp_cap, FrameCounters *counters) {
-    dim3 grid((kp_cap + RS_T - 1) / RS_T, nframes);
-    hipLaunchKernelGGL(k_rank_sort, grid, dim3(RS_T), 0, st, oriented, sorted, kp_cap, counters);
+                  uint8_t *flags, int kp_cap, FrameCounters *counters, int32_t *ranks) {
+    const int tiles = (kp_cap + RS_T - 1) / RS_T;
+    if (ranks) {
+        hipMemsetAsync(ranks, 0, (size_t)nframes * kp_cap * sizeof(int32_t), st);
+        hipLaunchKernelGGL(k_rank_sort<true>, dim3(tiles, 8, nframes), dim3(RS_T), 0, st, oriented, sorted, kp_cap, counters, ranks);
+        hipLaunchKernelGGL(k_rank_scatter, dim3((kp_cap + 255) / 256, nframes), dim3(256), 0, st, oriented, sorted, kp_cap,
+                           counters, ranks);
+    } else {
+        hipLaunchKernelGGL(k_rank_sort<false>, dim3(tiles, nframes), dim3(RS_T), 0, st, oriented, sorted, kp_cap, counters,
+                           (int32_t *)nullptr);
+    }
     hipLaunchKernelGGL(k_unique_finalize, dim3(nframes), dim3(1024), 0, st, sorted, final_kp, flags, kp_cap, counters);
 }
 

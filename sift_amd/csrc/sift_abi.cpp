@@ -486,13 +486,16 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_e
                 TIMED(SIFT_STAGE_EXTREMA, launch_extrema_gradients(st, b->pyr, o, n, b->d_cand, b->cand_cap, b->d_counters));
     }
     TIMED(SIFT_STAGE_LOCALIZE, launch_localize_orient(st, b->pyr, n, b->d_cand, b->cand_cap, b->d_sorted, b->d_oriented,
-                                                      b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames));
+                                                      b->kp_cap, b->d_counters, b->d_cursors + 2 * b->max_frames, two_streams));
     if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[2], st));
     TIMED(SIFT_STAGE_CLEAN,
-          launch_clean(st, n, b->d_oriented, b->d_sorted, b->d_final, b->d_flags, b->kp_cap, b->d_counters));
+          launch_clean(st, n, b->d_oriented, b->d_sorted, b->d_final, b->d_flags, b->kp_cap, b->d_counters,
+                       // the descriptor array is not written before the next stage: it takes the partial ranks
+                       two_streams ? reinterpret_cast<int32_t *>(b->d_desc) : nullptr));
     if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[3], st));
     TIMED(SIFT_STAGE_DESCRIPTOR, launch_descriptors(st, b->pyr, n, b->d_final, b->kp_cap, b->d_counters,
-                                                    b->d_cursors + b->max_frames, b->d_desc, two_streams));
+                                                    b->d_cursors + b->max_frames, b->d_desc,
+                                                    times ? ((int64_t)1 << 40) : (int64_t)n * b->w * b->h));
     if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[4], st));
 #undef TIMED
     HIP_TRY(hipGetLastError());
