@@ -1,8 +1,8 @@
 // 4x4x8 descriptors: get_descriptors_parallel::operator() (sift.cpp:464-584).
 //
-// One 128-thread workgroup per keypoint; workgroups pull keypoints from a
-// per-frame cursor.  Each of its two waves takes every second row of the
-// (2*half_width+1)^2 window.  For a row, the columns that can pass the
+// One workgroup of two waves per keypoint (four or eight in launches of one or a few
+// frames); workgroups pull keypoints from a per-frame cursor.  Wave k of n takes
+// rows k, k + n, ... of the (2*half_width+1)^2 window.  For a row, the columns that can pass the
 // rotated-window test of sift.cpp:503 form an interval (two strips
 // -1 < s*j + B < 4 intersected); the wave sweeps only that interval, widened by
 // one pixel, with lanes on consecutive columns (coalesced reads), and every sample still takes
@@ -16,8 +16,8 @@
 // atomics.  Only the inner 4x4x8 bins are kept (the border ring of the 6x6x8
 // tensor is discarded by sift.cpp:557-563, so contributions to it are never
 // issued), and there is one 128-bin copy per (wave, lane & 7) so that
-// neighbouring pixels, which mostly share a bin, rarely collide.  The 16
-// copies are summed in fixed order, then normalised, clipped at 0.2*norm,
+// neighbouring pixels, which mostly share a bin, rarely collide.  The
+// copies (8 per wave) are summed in fixed order, then normalised, clipped at 0.2*norm,
 // scaled by 512 and rounded exactly as sift.cpp:564-573 does.  Output is one
 // byte per bin (values 0..255; at most 102 in practice).
 #include "common.h"

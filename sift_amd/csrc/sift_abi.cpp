@@ -422,9 +422,10 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_e
     const uint8_t *frames = b->d_ext_frames ? b->d_ext_frames : b->d_frames;
     // A workload that does not fill the chip (a single frame, a few small ones) is bound by the latency of its
     // ~70 dependent launches.  Only levels 1-3 of an octave feed the next octave, so the main stream runs base and
-    // levels 1-3 octave after octave while a second stream takes levels 4-5, the gradient planes and the extrema scan
-    // of each finished octave: about half as many launches on the critical path.  Large batches keep the plain order
-    // (their launches fill the chip, and the profiled pass times each launch on its own).
+    // levels 1-3 octave after octave while two side streams take levels 4-5, the gradient planes and the extrema scan
+    // of each finished octave: about half as many launches on the critical path.  The per-keypoint stages run the
+    // variants that give a keypoint more lanes.  Large batches keep the plain order (their launches fill the chip,
+    // and the profiled pass times each launch on its own).
     const bool two_streams = !times && (int64_t)n * b->w * b->h <= ((int64_t)1 << 22);
     group_events = group_events && !times;
     if (group_events) {
