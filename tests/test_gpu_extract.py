@@ -143,6 +143,28 @@ def test_batch_equals_single_and_is_deterministic(sift_lib, ctx):
         assert np.array_equal(kp, second[i][0]) and np.array_equal(desc, second[i][1])
 
 
+def test_batch_schedule_equals_latency_schedule(sift_lib, ctx):
+    """A launch of more than 4 M pixels takes the plain launch order and the two-wave per-keypoint kernels, a single
+    frame the side streams, the fused small-octave kernel and the wider per-keypoint kernels: the same frames must
+    come out the same either way (the profiled pass is the plain order as well)."""
+    w, h, n = 1280, 720, 6
+    frames = [sift_lib.synth_dead_leaves(70, i, w, h) for i in range(n)]
+    single = [ctx.extract(f) for f in frames]
+    b = ctx.batch(w, h, n)
+    for i, f in enumerate(frames):
+        b.upload(i, f)
+    b.run(n)
+    plain = [b.download(i) for i in range(n)]
+    b.run_profiled(n)
+    profiled = [b.download(i) for i in range(n)]
+    b.close()
+    for i in range(n):
+        assert len(single[i][0]) > 500
+        for kp, desc in (plain[i], profiled[i]):
+            assert np.array_equal(kp, single[i][0])
+            assert np.array_equal(desc, single[i][1].astype(np.uint8))
+
+
 def test_keypoints_are_sorted_and_unique_like_the_reference(ctx, golden):
     kp, _, _ = ctx.extract(golden("lenna")["gray"])
     # comparator of sift.cpp:204-213 (coordinates already halved, which preserves order)
