@@ -8,17 +8,20 @@
 //   d2(q,t) = |q|^2 + |t|^2 - 2 q.t
 //           = |q|^2 + [ |t|^2 - C*sum(t) ] + sum_k (C - 2 q_k) t_k,   C = 126
 //
-// (C - 2 q_k) fits a signed byte for q_k in [0,127], so one
-// v_mfma_i32_32x32x32_i8 chain over K = 128 with the bracket ("train bias")
+// (C - 2 q_k) fits a signed byte for q_k in [0,127], so a chain of two
+// v_mfma_i32_16x16x64_i8 over K = 128 with the bracket ("train bias")
 // preloaded into the accumulator yields s = d2 - |q|^2 directly, which ranks
-// train rows identically for a fixed query.
+// train rows identically for a fixed query.  (The 16x16x64 shape, not 32x32x32:
+// under this part's clock management a bare loop of the former sustains 4.1 P op/s
+// on random operands, of the latter 3.45, scripts/ubench/mfma_i8_shapes.hip.)
 //
 // Orientation: train rows are the MFMA rows (A operand, streamed through LDS),
 // queries are the columns (B operand, held in registers for the whole scan), so
-// a lane owns one query and its 16 accumulator registers are 16 train rows.
-// The common case costs a 16-way integer min and one compare per 32x32 block:
-// only when some lane's minimum beats its current second-best does the block's
-// accumulator go through the exact update path.  Ties resolve to the smaller train index.
+// a lane owns one query of a 16-query block and its 4 accumulator registers are 4 of the
+// block's 16 train rows.  The common case costs a 4-way integer min, one compare and a
+// vote per 16x16 tile: only when some lane's minimum beats its query's current
+// second-best does the tile's accumulator go through the exact update path.  Ties
+// resolve to the smaller train index.
 #include <limits.h>
 
 #include <mutex>
@@ -39,11 +42,10 @@ namespace {
 
 
 using v4i = __attribute__((ext_vector_type(4))) int;
-using v16i = __attribute__((ext_vector_type(16))) int;
 
-constexpr int TT = 128;     // train rows per LDS tile
-constexpr int QB = 4;       // 32-query column blocks per wave
-constexpr int QPB = 4 * QB * 32;  // queries per 256-thread workgroup
+constexpr int TT = 256;     // train rows per LDS tile
+constexpr int QB = 8;       // 16-query column blocks per wave
+constexpr int QPB = 4 * QB * 16;  // queries per 256-thread workgroup
 constexpr int C_OFF = 126;
 
 // train bias |t|^2 - C*sum(t), one thread per row
@@ -90,19 +92,19 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
     __shared__ int s_bias[2][TT];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int h = lane >> 5, c = lane & 31;
+    const int g = lane >> 4, c = lane & 15;  // k-group / row-group of the lane, column of its query in a block
 
-    // ---- query fragments (B operand): lane holds 16 k-values of its query per k-step
-    v4i bf[QB][4];
+    // ---- query fragments (B operand): lane holds 16 k-values of its query per k-step of 64
+    v4i bf[QB][2];
     int qnorm[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
-        const int qi = blockIdx.x * QPB + wv * (QB * 32) + qb * 32 + c;
+        const int qi = blockIdx.x * QPB + wv * (QB * 16) + qb * 16 + c;
         int nrm = 0;
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
+        for (int ks = 0; ks < 2; ks++) {
             uint4 raw = make_uint4(0, 0, 0, 0);
-            if (qi < nq) raw = *reinterpret_cast<const uint4 *>(q + (size_t)qi * 128 + ks * 32 + h * 16);
+            if (qi < nq) raw = *reinterpret_cast<const uint4 *>(q + (size_t)qi * 128 + ks * 64 + g * 16);
             const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
             v4i f;
 #pragma unroll
@@ -118,13 +120,14 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
             }
             bf[qb][ks] = f;
         }
+        nrm += __shfl_xor(nrm, 16);
         nrm += __shfl_xor(nrm, 32);
         qnorm[qb] = nrm;
     }
 
-    // Each query is scanned by two lanes (lane and lane ^ 32), each over half of the rows of a
-    // block with its own running top-2 (b1 <= b2).  thr is the second smallest of the four
-    // values the pair holds: a row at or above it cannot be in the query's final top-2 (an
+    // Each query is scanned by four lanes (lane ^ 16, ^ 32, ^ 48), each over a quarter of the rows of a
+    // block with its own running top-2 (b1 <= b2).  thr is the second smallest of the eight
+    // values the four hold: a row at or above it cannot be in the query's final top-2 (an
     // equal distance loses to the smaller index already held), so it gates the update path.
     int b1[QB], b2[QB], i1[QB], i2[QB], thr[QB];
 #pragma unroll
@@ -137,15 +140,16 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
     const int tile_begin = blockIdx.y * tiles_per_split;
     const int tile_end = min(ntiles, tile_begin + tiles_per_split);
 
-    uint4 stage[4];
+    constexpr int NST = TT * 8 / 256;  // 16-byte pieces of a tile per thread
+    uint4 stage[NST];
     int stage_bias = INT_MAX;
     auto fetch = [&](int tile) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int g = tid + 256 * u;
-            const int row = tile * TT + (g >> 3);
+        for (int u = 0; u < NST; u++) {
+            const int e = tid + 256 * u;
+            const int row = tile * TT + (e >> 3);
             stage[u] = make_uint4(0, 0, 0, 0);
-            if (row < nt) stage[u] = *reinterpret_cast<const uint4 *>(t + (size_t)row * 128 + (g & 7) * 16);
+            if (row < nt) stage[u] = *reinterpret_cast<const uint4 *>(t + (size_t)row * 128 + (e & 7) * 16);
         }
         if (tid < TT) {
             const int row = tile * TT + tid;
@@ -154,9 +158,9 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int g = tid + 256 * u;
-            const int row = g >> 3, chunk = g & 7;
+        for (int u = 0; u < NST; u++) {
+            const int e = tid + 256 * u;
+            const int row = e >> 3, chunk = e & 7;
             s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))] = stage[u];
         }
         if (tid < TT) s_bias[buf][tid] = stage_bias;
@@ -171,48 +175,34 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
     for (int tile = tile_begin; tile < tile_end; tile++) {
         const int buf = (tile - tile_begin) & 1;
         if (tile + 1 < tile_end) fetch(tile + 1);
-        // Pass over the tile.  A chain's accumulator goes through the exact update only when some lane's minimum
-        // of its 16 rows beats that lane's threshold (a wave-uniform branch, rarely taken once the thresholds
-        // have tightened); the accumulator is still live at that point, so nothing is recomputed.
+        // Pass over the tile, 16 train rows at a time.  A block of rows is eight chains of two MFMAs, one chain
+        // per 16-query block; a chain's accumulator (this lane's four rows of its query) goes through the exact
+        // update only when some lane's minimum beats that lane's threshold (a wave-uniform branch, rarely taken
+        // once the thresholds have tightened), while it is still live.
         //
-        // The pass is software-pipelined by hand, one scheduling fence per MFMA: in the shadow of each MFMA the
-        // wave issues either two LDS reads of the next block's operands or a third of one chain's 16-way
-        // minimum (three vector instructions), and a chain's minimum is only started two MFMAs after the
-        // chain's last one, when its result has left the matrix pipe.  MFMA order within a block of four
-        // chains c0..c3 (one per 32-query block): c0.1 c1.1 c2.1 | c0.2-4 | c3.1 | c1.2-4 | c2.2-4 | c3.2-4, so that
-        // the bias registers (the C operand of each chain's first MFMA) are free for the next block's after the
-        // seventh MFMA and chain c3 of the previous block can be reduced under the first six.
+        // The pass is software-pipelined by hand, one scheduling fence per MFMA: behind the first MFMA of a
+        // chain the wave issues one LDS read of the next block's operands (first three chains), behind the
+        // second the minimum of the chain before (two vector instructions, a compare and a vote), whose
+        // result has left the matrix pipe by then.
         auto load_af = [&](int rb, int ks, v4i &dst) {
-            const int row = rb * 32 + c, chunk = ks * 2 + h;
+            const int row = rb * 16 + c, chunk = ks * 4 + g;
             const uint4 a = s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))];
             dst = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
         };
-        auto load_bias = [&](int rb, int g, v16i &cinit) {
-            const int4 bb = *reinterpret_cast<const int4 *>(&s_bias[buf][rb * 32 + 8 * g + 4 * h]);
-            cinit[4 * g + 0] = bb.x;
-            cinit[4 * g + 1] = bb.y;
-            cinit[4 * g + 2] = bb.z;
-            cinit[4 * g + 3] = bb.w;
+        auto load_bias = [&](int rb, v4i &dst) {  // rows 4 g .. 4 g + 3 of the block: this lane's accumulator rows
+            const int4 bb = *reinterpret_cast<const int4 *>(&s_bias[buf][rb * 16 + 4 * g]);
+            dst = v4i{bb.x, bb.y, bb.z, bb.w};
         };
-        auto half_min = [](const v16i &a, int o, int &x, int &y) {  // three instructions: min of 8 left in two
-            const int t = min(min(a[o], a[o + 1]), a[o + 2]);
-            x = min(min(a[o + 3], a[o + 4]), a[o + 5]);
-            y = min(min(a[o + 6], a[o + 7]), t);
-            asm volatile("" : "+v"(x), "+v"(y));  // evaluated here, not where the values are consumed
-        };
-        // Exact update of query block qb with the 16 rows a lane holds of train block rb (still in the chain's
-        // accumulator when its minimum is known), row by row in ascending order (a lane's first of equal
-        // distances stays) with a wave vote per row; then the two lanes of each query exchange their best two
-        // for the new threshold.  Visiting only the row groups whose partial minimum qualifies, and exchanging
-        // through v_permlane32_swap instead of LDS, measured the same (26.1 against 25.8 ms).
-        auto exact_update = [&](const v16i &a, int qb, int rb) {
-            const int idx0 = tile * TT + rb * 32 + 4 * h;
+        // Exact update of query block qb with the four rows a lane holds of train block rb, in ascending order
+        // (a lane's first of equal distances stays) with a wave vote per row; then the four lanes of each query
+        // merge their best two, pair by pair, for the new threshold.
+        auto exact_update = [&](const v4i &a, int qb, int rb) {
+            const int idx0 = tile * TT + rb * 16 + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < 4; r++) {
                 const int sv = a[r];
-                // most rows lose against the running second-best in every lane: skip them whole
                 if (__any(sv < thr[qb])) {
-                    const int idx = idx0 + (r & 3) + 8 * (r >> 2);
+                    const int idx = idx0 + r;
                     if (sv < b1[qb]) {
                         b2[qb] = b1[qb]; i2[qb] = i1[qb]; b1[qb] = sv; i1[qb] = idx;
                     } else if (sv < b2[qb]) {
@@ -220,132 +210,95 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
                     }
                 }
             }
-            const int p1 = __shfl_xor(b1[qb], 32), p2 = __shfl_xor(b2[qb], 32);
-            thr[qb] = min(max(b1[qb], p1), min(b2[qb], p2));
+            const int p1 = __shfl_xor(b1[qb], 16), p2 = __shfl_xor(b2[qb], 16);
+            const int t1 = min(b1[qb], p1), t2 = min(max(b1[qb], p1), min(b2[qb], p2));  // best two of the pair
+            const int u1 = __shfl_xor(t1, 32), u2 = __shfl_xor(t2, 32);
+            thr[qb] = min(max(t1, u1), min(t2, u2));
         };
-        auto finish = [&](int x1, int y1, int x2, int y2, const v16i &a, int qb, int rb) {
-            const int m = min(min(min(x1, y1), x2), y2);
-            if (__any(m < thr[qb])) exact_update(a, qb, rb);
+        // A chain is looked at two chains later, when its result has long left the matrix pipe: its minimum
+        // (two vector instructions, pinned where they are written) behind the first MFMA of that chain, the
+        // compare and the vote behind the second, so that neither gap holds more than the MFMA beside it
+        // covers.  The branch is taken once per four chains, on the union of their votes.
+        v4i acc[QB];
+        int mins[QB];
+        unsigned long long votes = 0;
+        auto note_min = [&](int qb) {
+            int m = min(min(min(acc[qb][0], acc[qb][1]), acc[qb][2]), acc[qb][3]);
+            asm volatile("" : "+v"(m));
+            mins[qb] = m;
         };
-        static_assert(QB == 4, "the schedule below is written for four chains");
-        constexpr int NB = TT / 32;
-        v4i af[4], afn[4];
-        v16i cinit;
-        v16i acc[QB];
-        int lo2[2], hi2[2], lo3[2], hi3[2];  // halves of the minima of chains 2 and 3, carried into the next block
+        auto note_vote = [&](int qb) { votes |= __ballot(mins[qb] < thr[qb]); };
+        auto settle = [&](int q0, int rb) {  // chains q0 .. q0 + 3 of block rb
+            if (votes != 0) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) load_af(0, ks, af[ks]);
-#pragma unroll
-        for (int g = 0; g < 4; g++) load_bias(0, g, cinit);
+                for (int k = 0; k < 4; k++)
+                    if (__any(mins[q0 + k] < thr[q0 + k])) exact_update(acc[q0 + k], q0 + k, rb);
+                votes = 0;
+            }
+        };
+        constexpr int NB = TT / 16;
+        static_assert(QB == 8, "the schedule below settles the chains in two groups of four");
+        v4i af[2], afn[2], cinit, cinitn;
+        load_af(0, 0, af[0]);
+        load_af(0, 1, af[1]);
+        load_bias(0, cinit);
 #define SA_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define SA_MFMA(qb, ks, cin) acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks], bf[qb][ks], cin, 0, 0, 0)
 #pragma unroll
         for (int rb = 0; rb < NB; rb++) {
-            const bool prev = rb > 0, more = rb + 1 < NB;
-            int lo0[2], hi0[2], lo1[2], hi1[2];
-            SA_FENCE();
-            SA_MFMA(0, 0, cinit);
-            SA_FENCE();
-            if (prev) finish(lo2[0], lo2[1], hi2[0], hi2[1], acc[2], 2, rb - 1);
-            SA_FENCE();
-            SA_MFMA(1, 0, cinit);
-            SA_FENCE();
-            if (more) {
-                load_af(rb + 1, 0, afn[0]);
-                load_af(rb + 1, 1, afn[1]);
-            }
-            SA_FENCE();
-            SA_MFMA(2, 0, cinit);
-            SA_FENCE();
-            if (prev) half_min(acc[3], 0, lo3[0], lo3[1]);
-            SA_FENCE();
-            SA_MFMA(0, 1, acc[0]);
-            SA_FENCE();
-            if (prev) half_min(acc[3], 8, hi3[0], hi3[1]);
-            SA_FENCE();
-            SA_MFMA(0, 2, acc[0]);
-            SA_FENCE();
-            if (prev) finish(lo3[0], lo3[1], hi3[0], hi3[1], acc[3], 3, rb - 1);
-            SA_FENCE();
-            SA_MFMA(0, 3, acc[0]);
-            SA_FENCE();
-            if (more) {
-                load_af(rb + 1, 2, afn[2]);
-                load_af(rb + 1, 3, afn[3]);
-            }
-            SA_FENCE();
-            SA_MFMA(3, 0, cinit);
-            SA_FENCE();
-            if (more) {
-                load_bias(rb + 1, 0, cinit);
-                load_bias(rb + 1, 1, cinit);
-            }
-            SA_FENCE();
-            SA_MFMA(1, 1, acc[1]);
-            SA_FENCE();
-            if (more) {
-                load_bias(rb + 1, 2, cinit);
-                load_bias(rb + 1, 3, cinit);
-            }
-            SA_FENCE();
-            SA_MFMA(1, 2, acc[1]);
-            SA_FENCE();
-            half_min(acc[0], 0, lo0[0], lo0[1]);
-            SA_FENCE();
-            SA_MFMA(1, 3, acc[1]);
-            SA_FENCE();
-            half_min(acc[0], 8, hi0[0], hi0[1]);
-            SA_FENCE();
-            SA_MFMA(2, 1, acc[2]);
-            SA_FENCE();
-            finish(lo0[0], lo0[1], hi0[0], hi0[1], acc[0], 0, rb);
-            SA_FENCE();
-            SA_MFMA(2, 2, acc[2]);
-            SA_FENCE();
-            half_min(acc[1], 0, lo1[0], lo1[1]);
-            SA_FENCE();
-            SA_MFMA(2, 3, acc[2]);
-            SA_FENCE();
-            half_min(acc[1], 8, hi1[0], hi1[1]);
-            SA_FENCE();
-            SA_MFMA(3, 1, acc[3]);
-            SA_FENCE();
-            finish(lo1[0], lo1[1], hi1[0], hi1[1], acc[1], 1, rb);
-            SA_FENCE();
-            SA_MFMA(3, 2, acc[3]);
-            SA_FENCE();
-            half_min(acc[2], 0, lo2[0], lo2[1]);
-            SA_FENCE();
-            SA_MFMA(3, 3, acc[3]);
-            SA_FENCE();
-            half_min(acc[2], 8, hi2[0], hi2[1]);
-            SA_FENCE();
-            if (more) {
+            const bool more = rb + 1 < NB;
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) af[ks] = afn[ks];
+            for (int qb = 0; qb < QB; qb++) {
+                const int look = (qb + QB - 2) % QB;            // the chain two back: 6, 7 of the block before, then 0..5
+                const bool have = qb >= 2 || rb > 0;
+                SA_FENCE();
+                acc[qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[qb][0], cinit, 0, 0, 0);
+                SA_FENCE();
+                if (have) note_min(look);
+                if (more) {
+                    if (qb == 2) load_af(rb + 1, 0, afn[0]);
+                    if (qb == 3) load_af(rb + 1, 1, afn[1]);
+                    if (qb == 4) load_bias(rb + 1, cinitn);
+                }
+                SA_FENCE();
+                acc[qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[qb][1], acc[qb], 0, 0, 0);
+                SA_FENCE();
+                if (have) {
+                    note_vote(look);
+                    if (qb == 5) settle(0, rb);                 // chains 0..3 of this block
+                    if (qb == 1) settle(4, rb - 1);             // chains 4..7 of the block before, still intact
+                }
+            }
+            SA_FENCE();
+            if (more) {
+                af[0] = afn[0];
+                af[1] = afn[1];
+                cinit = cinitn;
             }
         }
-        finish(lo2[0], lo2[1], hi2[0], hi2[1], acc[2], 2, NB - 1);
-        half_min(acc[3], 0, lo3[0], lo3[1]);
-        half_min(acc[3], 8, hi3[0], hi3[1]);
-        finish(lo3[0], lo3[1], hi3[0], hi3[1], acc[3], 3, NB - 1);
+        note_min(QB - 2);
+        note_vote(QB - 2);
+        note_min(QB - 1);
+        note_vote(QB - 1);
+        settle(4, NB - 1);
         SA_FENCE();
-#undef SA_MFMA
 #undef SA_FENCE
         if (tile + 1 < tile_end) commit(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- merge the two lane halves of each query, add |q|^2, store
+    // ---- merge the four lanes of each query (pair by pair), add |q|^2, store
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
-        const int pb1 = __shfl_xor(b1[qb], 32), pi1 = __shfl_xor(i1[qb], 32);
-        const int pb2 = __shfl_xor(b2[qb], 32), pi2 = __shfl_xor(i2[qb], 32);
         int r1 = b1[qb], j1 = i1[qb], r2 = b2[qb], j2 = i2[qb];
-        top2_insert(pb1, pi1, r1, j1, r2, j2);
-        top2_insert(pb2, pi2, r1, j1, r2, j2);
-        const int qi = blockIdx.x * QPB + wv * (QB * 32) + qb * 32 + c;
-        if (h == 0 && qi < nq) {
+#pragma unroll
+        for (int step = 16; step <= 32; step *= 2) {
+            const int pb1 = __shfl_xor(r1, step), pi1 = __shfl_xor(j1, step);
+            const int pb2 = __shfl_xor(r2, step), pi2 = __shfl_xor(j2, step);
+            top2_insert(pb1, pi1, r1, j1, r2, j2);
+            top2_insert(pb2, pi2, r1, j1, r2, j2);
+        }
+        const int qi = blockIdx.x * QPB + wv * (QB * 16) + qb * 16 + c;
+        if (g == 0 && qi < nq) {
             sift_knn2 o;
             o.d1 = j1 >= 0 ? r1 + qnorm[qb] : INT_MAX;
             o.i1 = j1 >= 0 ? j1 + train_base : -1;
