@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
         // (a lane's first of equal distances stays) with a wave vote per row; then the four lanes of each query
         // merge their best two, pair by pair, for the new threshold.
         auto exact_update = [&](const v4i &a, int qb, int rb) {
-            const int idx0 = tile * TT + rb * 16 + 4 * g;
+            int idx0 = tile * TT + rb * 16 + 4 * g;
+            asm volatile("" : "+v"(idx0));  // formed here: hoisted above the branch, the row indices cost every tile four instructions
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int sv = a[r];
