@@ -418,8 +418,9 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
         uint8_t *dacc;
     };
     std::vector<Ptrs> P((size_t)ngpu);
-    // 1. operands up, local top-2 with global train indices
-    for (int r = 0; r < ngpu; r++) {
+    // 1. operands up, local top-2 with global train indices.  Copies out of pageable memory return when the data has
+    // left the caller's buffer, so one host thread would feed the GPUs one after the other: every GPU has its own.
+    auto feed = [&](int r) -> int {
         sift_ctx *c = g->ctx[r];
         HIP_TRY(hipSetDevice(c->device));
         const int64_t nr = bounds[r + 1] - bounds[r];
@@ -427,7 +428,8 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
         const size_t need = qb + tb + 2 * partb + outb + up256((size_t)slice);
         if (need > g->knn[r].bytes) {
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if ((rc = ensure_bytes(&g->knn[r].buf, &g->knn[r].bytes, need))) return rc;
+            const int grow = ensure_bytes(&g->knn[r].buf, &g->knn[r].bytes, need);
+            if (grow) return grow;
         }
         char *base = static_cast<char *>(g->knn[r].buf);
         Ptrs &p = P[r];
@@ -441,7 +443,22 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
         if (nr > 0) HIP_TRY(hipMemcpyAsync(p.dt, t + (size_t)bounds[r] * 128, (size_t)nr * 128, hipMemcpyHostToDevice, c->stream));
         // records past the last query (the last slice is padded to the common length) carry index -1: the merge skips them
         HIP_TRY(hipMemsetAsync(p.part, 0xff, (size_t)ngpu * slice * rec, c->stream));
-        if ((rc = sift_knn2_device(c, p.dq, nq, p.dt, (int)nr, (int)bounds[r], p.part))) return rc;
+        return sift_knn2_device(c, p.dq, nq, p.dt, (int)nr, (int)bounds[r], p.part);
+    };
+    if (ngpu == 1) {
+        if ((rc = feed(0))) return rc;
+    } else {
+        std::vector<int> frc((size_t)ngpu, SIFT_OK);
+        std::vector<std::string> fmsg((size_t)ngpu);
+        std::vector<std::thread> th;
+        for (int r = 0; r < ngpu; r++)
+            th.emplace_back([&, r] {
+                frc[r] = feed(r);
+                if (frc[r]) fmsg[r] = sift_last_error();  // the message is the failing thread's
+            });
+        for (auto &x : th) x.join();
+        for (int r = 0; r < ngpu; r++)
+            if (frc[r]) return fail(frc[r], "GPU " + std::to_string(g->ctx[r]->device) + ": " + fmsg[r]);
     }
     // 2. slice s of every GPU's partial results goes to GPU s
     ncclResult_t e = g->rccl.GroupStart();
