@@ -54,7 +54,7 @@ void launch_descriptor_work(hipStream_t st, const Pyramid &p, int nframes, const
 // kernels_knn.hip
 size_t knn_scratch_bytes(int nq, int nt);
 // Size of the file-scope device array behind sift_knn2_device_noalloc.  Partial results need at most
-// 8,380,416 bytes whatever nq is (at most 523,776 split x query records of 16 bytes), train biases 4 bytes per row.
+// 8,355,840 bytes whatever nq is (at most 522,240 split x query records of 16 bytes), train biases 4 bytes per row.
 constexpr size_t KNN_STATIC_SCRATCH_BYTES = (size_t)16 << 20;
 hipError_t knn_static_scratch(int device, void **ptr);
 void launch_knn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int train_base, sift_knn2 *out,

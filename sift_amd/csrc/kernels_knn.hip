@@ -45,7 +45,12 @@ using v4i = __attribute__((ext_vector_type(4))) int;
 
 constexpr int TT = 256;     // train rows per LDS tile
 constexpr int QB = 8;       // 16-query column blocks per wave
-constexpr int QPB = 4 * QB * 16;  // queries per 256-thread workgroup
+// Eight waves share every tile: a workgroup of four re-reads the train set once per 512 queries, and that traffic
+// (L2 -> registers -> LDS) costs the matrix pipe a seventh of its rate; with eight it is halved (24.5 -> 22.4 ms at
+// 262,144 x 1,048,576).  One such workgroup fills a CU (two waves per SIMD at this register count).
+constexpr int KW = 8;        // waves per workgroup
+constexpr int KT = 64 * KW;
+constexpr int QPB = KW * QB * 16;  // queries per workgroup
 constexpr int C_OFF = 126;
 
 // train bias |t|^2 - C*sum(t), one thread per row
@@ -85,7 +90,7 @@ __device__ __forceinline__ void top2_insert(int s, int idx, int &b1, int &i1, in
 
 // grid.x = query blocks, grid.y = train splits (each split scans a contiguous
 // range of tiles and writes its own partial result row).
-__global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
+__global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
                                                int nt, const int *__restrict__ tbias, int train_base,
                                                int tiles_per_split, sift_knn2 *__restrict__ out) {
     __shared__ uint4 s_tile[2][TT * 8];
@@ -140,13 +145,13 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
     const int tile_begin = blockIdx.y * tiles_per_split;
     const int tile_end = min(ntiles, tile_begin + tiles_per_split);
 
-    constexpr int NST = TT * 8 / 256;  // 16-byte pieces of a tile per thread
+    constexpr int NST = TT * 8 / KT;  // 16-byte pieces of a tile per thread
     uint4 stage[NST];
     int stage_bias = INT_MAX;
     auto fetch = [&](int tile) {
 #pragma unroll
         for (int u = 0; u < NST; u++) {
-            const int e = tid + 256 * u;
+            const int e = tid + KT * u;
             const int row = tile * TT + (e >> 3);
             stage[u] = make_uint4(0, 0, 0, 0);
             if (row < nt) stage[u] = *reinterpret_cast<const uint4 *>(t + (size_t)row * 128 + (e & 7) * 16);
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2(const uint8_t *__restrict__ q, 
     auto commit = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < NST; u++) {
-            const int e = tid + 256 * u;
+            const int e = tid + KT * u;
             const int row = e >> 3, chunk = e & 7;
             s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))] = stage[u];
         }
@@ -333,7 +338,7 @@ __global__ void k_knn2_merge(const sift_knn2 *__restrict__ parts, int nparts, in
 int choose_splits(int nq, int nt) {
     const int qblocks = (nq + QPB - 1) / QPB;
     const int ntiles = (nt + TT - 1) / TT;
-    int splits = (512 + qblocks - 1) / qblocks;  // at least two workgroups per CU
+    int splits = (256 + qblocks - 1) / qblocks;  // at least one workgroup per CU
     if (splits > ntiles) splits = ntiles;
     if (splits < 1) splits = 1;
     return splits;
@@ -379,9 +384,9 @@ void launch_knn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int
     const int tps = splits > 0 && ntiles > 0 ? (ntiles + splits - 1) / splits : 1;
     const int qblocks = (nq + QPB - 1) / QPB;
     if (splits == 1) {
-        hipLaunchKernelGGL(k_knn2, dim3(qblocks, 1), dim3(256), 0, st, q, nq, t, nt, bias, train_base, tps, out);
+        hipLaunchKernelGGL(k_knn2, dim3(qblocks, 1), dim3(KT), 0, st, q, nq, t, nt, bias, train_base, tps, out);
     } else {
-        hipLaunchKernelGGL(k_knn2, dim3(qblocks, splits), dim3(256), 0, st, q, nq, t, nt, bias, train_base, tps,
+        hipLaunchKernelGGL(k_knn2, dim3(qblocks, splits), dim3(KT), 0, st, q, nq, t, nt, bias, train_base, tps,
                            parts);
         hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, st, parts, splits, nq, out,
                            (uint8_t *)nullptr);
