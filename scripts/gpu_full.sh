@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round deliverables on the GPU box: full GPU test suite, smoke, the default
+# Evidence run on the GPU box: full GPU test suite, smoke, the default
 # bench under rocprofv3 --kernel-trace --stats --output-format csv, then HBM byte counters
 # (separate passes) for the extraction kernels and the 8-byte copy calibration.
 set -o pipefail

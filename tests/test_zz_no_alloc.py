@@ -1,7 +1,7 @@
 """sift_knn2_device_noalloc: the matcher entry point that allocates nothing (its scratch is a static device
 array inside the library) must give bit-for-bit the results of sift_knn2_device, call after call, whatever the
-previous call left in the shared scratch.  Collected last on purpose: the round's GPU run stops at the first
-failure."""
+previous call left in the shared scratch.  Collected last on purpose: a GPU run with -x stops at the first
+failure, which would hide every test after this one."""
 import numpy as np
 import pytest
 
