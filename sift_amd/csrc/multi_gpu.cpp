@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <vector>
 
 #include "abi_internal.h"
 
@@ -132,6 +133,7 @@ struct ExtractJob {
     size_t row_stride, frame_stride;
     int lo, hi;  // this GPU's frames [lo, hi)
     sift_frame_result *results;
+    bool ramp;   // the library chooses the launch sizes (the caller named none)
 };
 
 // Results of chunk `c` (frames first .. first + m) to the host: counts, then keypoints and descriptors of every
@@ -203,13 +205,40 @@ int pipe_download(sift_ctx *ctx, Pipe &p, int slot, const ExtractJob &job, int f
     return SIFT_OK;
 }
 
+// Launch sizes for `total` frames through workspaces of `cap` frames.  When the library chooses: a quarter-size launch first and last, so that the
+// GPU starts after a quarter of the staging and upload time of a full launch and the last download and unpacking,
+// which nothing overlaps, is a quarter as long; full or evenly cut launches between them.
+std::vector<int> launch_sizes(int total, int cap, bool ramp) {
+    std::vector<int> sizes;
+    if (total <= cap) {
+        if (total > 0) sizes.push_back(total);
+        return sizes;
+    }
+    if (!ramp) {  // the caller's launch size, the remainder last
+        for (int at = 0; at < total; at += cap) sizes.push_back(std::min(cap, total - at));
+        return sizes;
+    }
+    const int small = std::max(1, cap / 4);
+    int rest = total - small;
+    const int tail = rest > cap ? small : 0;
+    rest -= tail;
+    const int n = (rest + cap - 1) / cap;
+    sizes.push_back(small);
+    for (int i = 0; i < n; i++) sizes.push_back(rest / n + (i < rest % n ? 1 : 0));
+    if (tail) sizes.push_back(tail);
+    return sizes;
+}
+
 int pipe_run(sift_ctx *ctx, Pipe &p, const ExtractJob &job) {
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t px = (size_t)p.w * p.h;
-    const int nchunks = (job.hi - job.lo + p.chunk - 1) / p.chunk;
+    const std::vector<int> sizes = launch_sizes(job.hi - job.lo, p.chunk, job.ramp);
+    const int nchunks = (int)sizes.size();
+    std::vector<int> firsts((size_t)nchunks);
+    for (int k = 0, at = job.lo; k < nchunks; at += sizes[k], k++) firsts[k] = at;
     for (int k = 0; k < nchunks; k++) {
         const int slot = k & 1;
-        const int first = job.lo + k * p.chunk, m = std::min(p.chunk, job.hi - first);
+        const int first = firsts[k], m = sizes[k];
         sift_batch *b = p.ws[slot];
         // page-locked staging of chunk k (the transfer of chunk k-2 out of this buffer has completed: its run was
         // waited for when its results were taken)
@@ -245,14 +274,13 @@ int pipe_run(sift_ctx *ctx, Pipe &p, const ExtractJob &job) {
         if (rc) return rc;
         HIP_TRY(hipEventRecord(p.ev_run[slot], ctx->stream));
         if (k >= 1) {
-            const int pfirst = job.lo + (k - 1) * p.chunk;
-            rc = pipe_download(ctx, p, slot ^ 1, job, pfirst, std::min(p.chunk, job.hi - pfirst));
+            rc = pipe_download(ctx, p, slot ^ 1, job, firsts[k - 1], sizes[k - 1]);
             if (rc) return rc;
         }
     }
     if (nchunks >= 1) {
-        const int k = nchunks - 1, pfirst = job.lo + k * p.chunk;
-        int rc = pipe_download(ctx, p, k & 1, job, pfirst, std::min(p.chunk, job.hi - pfirst));
+        const int k = nchunks - 1;
+        int rc = pipe_download(ctx, p, k & 1, job, firsts[k], sizes[k]);
         if (rc) return rc;
     }
     return SIFT_OK;
@@ -342,7 +370,7 @@ int sift_extract_batch_u8(sift_group *g, const uint8_t *frames, int n, int w, in
         chunk = std::min(chunk, hi - lo);
         int e = pipe_prepare(g->ctx[r], g->pipe[r], w, h, std::max(chunk, g->pipe[r].w == w && g->pipe[r].h == h ? g->pipe[r].chunk : 0));
         if (!e) {
-            ExtractJob job{frames, row_stride, frame_stride, lo, hi, results};
+            ExtractJob job{frames, row_stride, frame_stride, lo, hi, results, frames_per_launch <= 0};
             e = pipe_run(g->ctx[r], g->pipe[r], job);
         }
         if (e) {

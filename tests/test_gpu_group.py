@@ -83,6 +83,23 @@ def test_frames_split_over_two_members_driven_by_two_host_threads(sift_lib, ctx)
         other.close()
 
 
+def test_library_chosen_launch_sizes_cover_every_frame_once(sift_lib, ctx):
+    """frames_per_launch = 0: the library cuts the run into a quarter-size launch, full ones and a quarter-size one
+    (4, 16, 15, 4 frames here); every frame's result must land at its index, whatever launch carried it."""
+    w, h, n = 160, 120, 39
+    frames = np.stack([sift_lib.synth_dead_leaves(11, i, w, h) for i in range(n)])
+    want = [ctx.extract(f) for f in frames]
+    g = sift_lib.Group([ctx])
+    try:
+        for count in (n, 17, 16, 5):
+            got = g.extract_batch(frames[:count], 0)
+            assert len(got) == count
+            for (kp, desc, _), (wkp, wdesc, _) in zip(got, want):
+                assert np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
+    finally:
+        g.close()
+
+
 def test_batch_extraction_reruns_frames_that_overflow_their_lists(sift_lib, ctx, oracle, lenna_bgr):
     gray = oracle.bgr_to_gray(lenna_bgr)
     frames = np.stack([gray, gray[::-1].copy()])
