@@ -40,7 +40,6 @@ void launch_clean(hipStream_t st, int nframes, const DevKeypoint *oriented, DevK
                   uint8_t *flags, int kp_cap, FrameCounters *counters, int32_t *ranks);
 
 // kernels_descriptor.hip
-int descriptor_init_attributes();
 // `launch_pixels` = frames x width x height of the launch: up to 1 M pixels keypoints get eight waves each, up to 4 M
 // four, beyond that two.
 void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,

@@ -12,14 +12,13 @@
 // per-keypoint table exp(-t^2/(8 w^2)) (the rotation preserves i^2+j^2), so
 // the loop has no transcendental.
 //
-// The eight trilinear contributions of a sample are scattered with LDS double
-// atomics.  Only the inner 4x4x8 bins are kept (the border ring of the 6x6x8
-// tensor is discarded by sift.cpp:557-563, so contributions to it are never
-// issued), and there is one 128-bin copy per (wave, lane & 7) so that
-// neighbouring pixels, which mostly share a bin, rarely collide.  The
-// copies (8 per wave) are summed in fixed order, then normalised, clipped at 0.2*norm,
-// scaled by 512 and rounded exactly as sift.cpp:564-573 does.  Output is one
-// byte per bin (values 0..255; at most 102 in practice).
+// The eight trilinear contributions of a sample are scattered with LDS 64-bit
+// integer atomics on a fixed-point tensor (see NCOPY and FX_ROW_EXP below).
+// Only the inner 4x4x8 bins are kept (the border ring of the 6x6x8 tensor is
+// discarded by sift.cpp:557-563, so contributions to it are never issued).  The
+// 16 copies are summed, converted back to double, then normalised, clipped at
+// 0.2*norm, scaled by 512 and rounded exactly as sift.cpp:564-573 does.  Output
+// is one byte per bin (values 0..255; at most 102 in practice).
 #include "common.h"
 #include "kernels.h"
 
@@ -32,17 +31,22 @@ constexpr int INNER = WINDOW_WIDTH * WINDOW_WIDTH * DBINS;  // 128
 // Waves per keypoint: two when the launch has keypoints enough to fill the chip (more waves per workgroup cost
 // throughput: 16.1 ms against 14.6 per 64 frames with four); four or eight for a launch of one or a few frames, where
 // the time of the stage is the time of its largest windows (a 512 x 512 frame: 169 us with two, 92 with four, 75-84
-// with eight; a 1080p frame has keypoints enough for four).  The copies are summed in one fixed order either way, but the
-// two orders differ, so a sum may differ in its last bits between the two.
+// with eight; a 1080p frame has keypoints enough for four).  The tensor sums are integers, so all three give the same
+// descriptor bit for bit.
 constexpr int NWAVES_BATCH = 2, NWAVES_SOME = 4, NWAVES_FEW = 8;
-constexpr int COPIES_PER_WAVE = 8;
 constexpr int ROWS_IN_FLIGHT = 4;
-constexpr int RS = WINDOW_WIDTH * DBINS, CS = DBINS;  // doubles between cell rows / cell columns of a tensor copy
-// Copies start two LDS bank pairs apart: equal bins of different copies then lie in different banks, and so do bins
-// that differ by one orientation step (the commonest difference between neighbouring pixels).  Measured per 64 1080p
-// frames: stride 129 15.5 ms, 130 14.6, 131..143 14.6-15.4, 132 16.5, 136 25.1, 144 43.3; padding the cell rows or
-// columns of a copy as well changes nothing.
-constexpr int CSTRIDE = INNER + 2;
+// The tensor exists in NCOPY copies, and a lane adds to copy (lane & 15).  The LDS takes a 64-bit atomic of a wave in
+// four passes of 16 consecutive lanes, and only lanes of one pass can collide: two of them on one address cost 12
+// clocks per instruction instead of 7.2, on one bank 8.0, and lanes of different passes never collide
+// (scripts/ubench/lds_atomic3.hip).  With 16 copies the lanes of a pass all use different copies, so no two of them
+// ever share an address; and with the copies interleaved (word index = bin * NCOPY + copy) a lane's bank is
+// 2 * copy + 32 * (bin & 1): different for every lane of a pass, whatever bins they hit.  Every atomic instruction
+// therefore runs at the conflict-free rate.  All waves of a workgroup share the 16 copies: integer sums do not depend
+// on the order in which the waves' additions arrive.
+constexpr int NCOPY = 16;
+constexpr int OS = NCOPY;                 // words between orientation bins
+constexpr int CS = DBINS * OS;            // between cell columns
+constexpr int RS = WINDOW_WIDTH * CS;     // between cell rows
 
 // Intersect [lo, hi] with { j : -1 < s*j + B < WINDOW_WIDTH }; `is` = 1/s.
 __device__ __forceinline__ void clip_strip(double s, double is, bool flat, double B, double &lo, double &hi) {
@@ -62,10 +66,20 @@ __device__ __forceinline__ double lane_broadcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-template <int NWAVES>
+// Contributions are accumulated as unsigned fixed point with LDS 64-bit integer atomics: integer sums do not depend
+// on the order of the additions, so every schedule of the kernel gives the same tensor.  The conversion costs
+// nothing: the two Gaussian weight factors carry powers of two that put magnitude = mag * w_row * w_col at
+// n * 2^-1074 with n the integer nearest mag * w * 2^k, i.e. in the subnormal range, where the bit pattern of a
+// double IS the integer n (and stays so up to n < 2^53).  The shares of the trilinear split are products and
+// differences of such values, so they are rounded to integers by the multiplier itself and the eight shares of a
+// sample add up to n exactly.  A gradient magnitude is below 2^9 and k <= 43, so n < 2^52.
+constexpr int FX_ROW_EXP = -500;  // the row weight carries 2^-500 (still a normal number), the column weight the rest
+
+__device__ __forceinline__ double pow2(int e) { return __longlong_as_double((long long)(1023 + e) << 52); }
+
 struct DescShared {
     double wtab[256];
-    double tensor[NWAVES * COPIES_PER_WAVE][CSTRIDE];  // after the copies are summed, its first 2*INNER doubles hold the sums and their squares
+    unsigned long long tensor[INNER * NCOPY];  // after the copies are summed, its first 2*INNER words hold the sums and their squares as doubles
     int idx;
 };
 
@@ -74,14 +88,13 @@ struct DescShared {
 // and the LDS double atomics they would issue (two per cell corner that lies inside the 4x4 grid), into
 // work[frame][0..1].  It exists so that the kernel's throughput can be stated in the unit that bounds it.
 template <bool COUNT, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
+__global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
                                                       const FrameCounters *__restrict__ counters,
                                                       int32_t *__restrict__ cursors, uint8_t *__restrict__ desc,
                                                       unsigned long long *__restrict__ work) {
-    constexpr int NT = NWAVES * 64, NCOPY = NWAVES * COPIES_PER_WAVE;
+    constexpr int NT = NWAVES * 64;
     static_assert(NT >= INNER, "one thread per bin in the normalisation");
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // 67 KB with eight waves: beyond the static limit
-    DescShared<NWAVES> &sm = *reinterpret_cast<DescShared<NWAVES> *>(dyn_lds);
+    __shared__ DescShared sm;
     const int f = blockIdx.y;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
     // not for memory, so the list order stays.
     for (;;) {
         if (tid == 0) sm.idx = atomicAdd(&cursors[f], 1);
-        for (int t = tid; t < NCOPY * CSTRIDE; t += NT) (&sm.tensor[0][0])[t] = 0.0;
+        for (int t = tid; t < INNER * NCOPY; t += NT) sm.tensor[t] = 0;
         __syncthreads();
         const int it = sm.idx;
         if (it >= n) break;
@@ -123,9 +136,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
                       sqrt((double)height * (double)height + (double)width * (double)width));  // sift.cpp:492-493
         const double inv_hw = 1.0 / hist_width;
         const double wscale = weight_multiplier * inv_hw * inv_hw;
+        // Fixed-point position: fewer than 2^lg samples of less than 2^9 each, so that no sum reaches 2^63.
+        const unsigned long long area = (unsigned long long)(2 * (long long)half_width + 1) * (unsigned long long)(2 * (long long)half_width + 1);
+        const int fx_bits = min(43, 54 - (64 - __builtin_clzll(area)));
+        // table entries: exp(..) * 2^(k - 1074 - FX_ROW_EXP) (column weights); a row weight is a table entry times
+        // 2^(FX_ROW_EXP - (k - 1074 - FX_ROW_EXP)) = exp(..) * 2^FX_ROW_EXP
+        const double col_scale = pow2(fx_bits - 1074 - FX_ROW_EXP);
+        const double row_scale = pow2(FX_ROW_EXP), tab_to_row = pow2(2 * FX_ROW_EXP + 1074 - fx_bits);
         const bool use_tab = half_width < 256;
         if (use_tab)
-            for (int t = tid; t <= half_width; t += NT) sm.wtab[t] = exp(wscale * (double)(t * t));
+            for (int t = tid; t <= half_width; t += NT) sm.wtab[t] = exp(wscale * (double)(t * t)) * col_scale;
         __syncthreads();
         // bin_row = (sin*j + cos*i)/hist_width + 1.5 = su*j + Bu(i); bin_col = (sin*i - cos*j)/hist_width + 1.5
         // = sv*j + Bv(i) (sift.cpp:497-501); a sample counts when both lie in (-1, 4) (sift.cpp:503).
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
         const double isu = flat_u ? 0.0 : 1.0 / su, isv = flat_v ? 0.0 : 1.0 / sv;
         const double half_bins = 0.5 * (WINDOW_WIDTH - 1);
         const double ang_bins = angle * bins_per_degree;
-        double *T = sm.tensor[wv * COPIES_PER_WAVE + (lane & (COPIES_PER_WAVE - 1))];
+        unsigned long long *T = sm.tensor + (lane & (NCOPY - 1));
         // image bounds on the column: 0 < pt_x + j < width - 1 (sift.cpp:506)
         const int jmin = max(-half_width, 1 - pt_x), jmax = min(half_width, width - 2 - pt_x);
         // Each wave takes rows wv, wv+NWAVES, ...  Row set-up (column interval, bin offsets, row
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
                         while (my_jlo <= my_jhi && !inside(my_jlo)) my_jlo++;
                         while (my_jhi >= my_jlo && !inside(my_jhi)) my_jhi--;
                     }
-                    my_wi = use_tab ? sm.wtab[min(abs(i), 255)] : exp(wscale * (double)(i * i));
+                    my_wi = use_tab ? sm.wtab[min(abs(i), 255)] * tab_to_row : exp(wscale * (double)(i * i)) * row_scale;
                 }
             }
             for (int g0 = 0; g0 < 64 && ib + g0 * NWAVES <= half_width; g0 += ROWS_IN_FLIGHT) {
@@ -214,19 +234,19 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
                         // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) (sift.cpp:512-517) as a product of two table entries
                         // a zero gradient adds +0.0 to eight bins, which leaves every one of them unchanged
                         if (g[r].mag == 0.0) continue;
-                        const double wcol = use_tab ? wj[r] : exp(wscale * (double)(j * j));
-                        const double magnitude = g[r].mag * (wi[r] * wcol);                  // sift.cpp:518
+                        const double wcol = use_tab ? wj[r] : exp(wscale * (double)(j * j)) * col_scale;
+                        const double magnitude = (g[r].mag * wi[r]) * wcol;                  // sift.cpp:518, as an integer * 2^-1074
                         const double orientation = g[r].ori * bins_per_degree - ang_bins;  // sift.cpp:519
                         const double fr = floor(bin_row), fc = floor(bin_col), fo = floor(orientation);
                         const int row_bin = (int)fr, col_bin = (int)fc;
                         const double row_pr = bin_row - fr, col_pr = bin_col - fc, ori_pr = orientation - fo;
-                        const int ob0 = (int)fo & (DBINS - 1), ob1 = ((int)fo + 1) & (DBINS - 1);
+                        const int ob0 = ((int)fo & (DBINS - 1)) * OS, ob1 = (((int)fo + 1) & (DBINS - 1)) * OS;
                         // trilinear split (sift.cpp:527-551): each step peels the upper share off the lower one
                         const double m1 = magnitude * row_pr, m0 = magnitude - m1;
                         const double m01 = m0 * col_pr, m00 = m0 - m01;
                         const double m11 = m1 * col_pr, m10 = m1 - m11;
                         // cell (row_bin + a, col_bin + b) of the inner 4x4 grid; the border ring is dropped
-                        double *cell = T + (row_bin * RS + col_bin * CS);
+                        unsigned long long *cell = T + (row_bin * RS + col_bin * CS);
                         const bool r0 = (unsigned)row_bin < (unsigned)WINDOW_WIDTH;
                         const bool r1 = (unsigned)(row_bin + 1) < (unsigned)WINDOW_WIDTH;
                         const bool c0 = (unsigned)col_bin < (unsigned)WINDOW_WIDTH;
@@ -238,23 +258,23 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
                         }
                         if (r0 && c0) {
                             const double hi = m00 * ori_pr;
-                            atomicAdd(cell + ob0, m00 - hi);
-                            atomicAdd(cell + ob1, hi);
+                            atomicAdd(cell + ob0, (unsigned long long)__double_as_longlong(m00 - hi));
+                            atomicAdd(cell + ob1, (unsigned long long)__double_as_longlong(hi));
                         }
                         if (r0 && c1) {
                             const double hi = m01 * ori_pr;
-                            atomicAdd(cell + CS + ob0, m01 - hi);
-                            atomicAdd(cell + CS + ob1, hi);
+                            atomicAdd(cell + CS + ob0, (unsigned long long)__double_as_longlong(m01 - hi));
+                            atomicAdd(cell + CS + ob1, (unsigned long long)__double_as_longlong(hi));
                         }
                         if (r1 && c0) {
                             const double hi = m10 * ori_pr;
-                            atomicAdd(cell + RS + ob0, m10 - hi);
-                            atomicAdd(cell + RS + ob1, hi);
+                            atomicAdd(cell + RS + ob0, (unsigned long long)__double_as_longlong(m10 - hi));
+                            atomicAdd(cell + RS + ob1, (unsigned long long)__double_as_longlong(hi));
                         }
                         if (r1 && c1) {
                             const double hi = m11 * ori_pr;
-                            atomicAdd(cell + RS + CS + ob0, m11 - hi);
-                            atomicAdd(cell + RS + CS + ob1, hi);
+                            atomicAdd(cell + RS + CS + ob0, (unsigned long long)__double_as_longlong(m11 - hi));
+                            atomicAdd(cell + RS + CS + ob1, (unsigned long long)__double_as_longlong(hi));
                         }
                     }
                 }
@@ -276,13 +296,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
         }
         __syncthreads();
         // inner 4x4x8 bins (sift.cpp:557-563), copies summed in fixed order
-        double *vals = &sm.tensor[0][0], *red = vals + INNER;
+        double *vals = reinterpret_cast<double *>(sm.tensor), *red = vals + INNER;
         double v = 0.0;
         if (tid < INNER) {
-            const int at = (tid >> 5) * RS + ((tid >> 3) & 3) * CS + (tid & 7);
-            v = sm.tensor[0][at];
-#pragma unroll 8
-            for (int c = 1; c < NCOPY; c++) v += sm.tensor[c][at];
+            // output bin tid = (cell row, cell column, orientation) is tensor bin tid: the copies of a bin are adjacent
+            unsigned long long total = 0;
+#pragma unroll
+            for (int c = 0; c < NCOPY; c++) total += sm.tensor[tid * NCOPY + ((c + tid) & (NCOPY - 1))];
+            v = (double)total * pow2(-fx_bits);
         }
         __syncthreads();  // every copy has been read: the tensor's storage is reused below
         if (tid < INNER) {
@@ -311,16 +332,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_descriptors(Pyramid p, const De
 
 }  // namespace
 
-int descriptor_init_attributes() {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_descriptors<false, NWAVES_FEW>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DescShared<NWAVES_FEW>));
-    return e == hipSuccess ? 0 : -1;
-}
-
 template <int NW>
 static void launch_descriptors_nw(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
                                   const FrameCounters *counters, int32_t *cursors, uint8_t *desc, int blocks) {
-    hipLaunchKernelGGL((k_descriptors<false, NW>), dim3(blocks, nframes), dim3(NW * 64), sizeof(DescShared<NW>), st, p, kps,
+    hipLaunchKernelGGL((k_descriptors<false, NW>), dim3(blocks, nframes), dim3(NW * 64), 0, st, p, kps,
                        kp_cap, counters, cursors, desc, (unsigned long long *)nullptr);
 }
 
@@ -337,7 +352,7 @@ void launch_descriptors(hipStream_t st, const Pyramid &p, int nframes, const Dev
 void launch_descriptor_work(hipStream_t st, const Pyramid &p, int nframes, const DevKeypoint *kps, int kp_cap,
                             const FrameCounters *counters, int32_t *cursors, unsigned long long *work) {
     dim3 grid(2048 / NWAVES_BATCH, nframes);
-    hipLaunchKernelGGL((k_descriptors<true, NWAVES_BATCH>), grid, dim3(NWAVES_BATCH * 64), sizeof(DescShared<NWAVES_BATCH>), st, p, kps, kp_cap, counters,
+    hipLaunchKernelGGL((k_descriptors<true, NWAVES_BATCH>), grid, dim3(NWAVES_BATCH * 64), 0, st, p, kps, kp_cap, counters,
                        cursors, (uint8_t *)nullptr, work);
 }
 

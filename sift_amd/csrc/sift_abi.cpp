@@ -114,7 +114,7 @@ int sift_ctx_create(int device, sift_ctx **out) {
         delete c;
         return fail(SIFT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    if (pyramid_init_attributes() != 0 || descriptor_init_attributes() != 0) {
+    if (pyramid_init_attributes() != 0) {
         hipStreamDestroy(c->stream);
         delete c;
         return fail(SIFT_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
