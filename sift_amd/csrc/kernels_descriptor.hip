@@ -2,11 +2,11 @@
 //
 // One workgroup of two waves per keypoint (four or eight in launches of one or a few
 // frames); workgroups pull keypoints from a per-frame cursor.  Wave k of n takes
-// rows k, k + n, ... of the (2*half_width+1)^2 window.  For a row, the columns that can pass the
+// rows k, k + n, ... of the (2*half_width+1)^2 window.  For a row, the columns that pass the
 // rotated-window test of sift.cpp:503 form an interval (two strips
-// -1 < s*j + B < 4 intersected); the wave sweeps only that interval, widened by
-// one pixel, with lanes on consecutive columns (coalesced reads), and every sample still takes
-// the exact test.  A sample's gradient magnitude and direction come from the
+// -1 < s*j + B < 4 intersected), found exactly when the row is set up; the wave sweeps
+// only the intervals, four rows side by side with 16 lanes on consecutive columns of
+// each.  A sample's gradient magnitude and direction come from the
 // precomputed gradient plane of the keypoint's Gaussian level, and its
 // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) is the product of two entries of a
 // per-keypoint table exp(-t^2/(8 w^2)) (the rotation preserves i^2+j^2), so
@@ -34,6 +34,9 @@ constexpr int INNER = WINDOW_WIDTH * WINDOW_WIDTH * DBINS;  // 128
 // with eight; a 1080p frame has keypoints enough for four).  The tensor sums are integers, so all three give the same
 // descriptor bit for bit.
 constexpr int NWAVES_BATCH = 2, NWAVES_SOME = 4, NWAVES_FEW = 8;
+// Gradient loads in flight per lane.  With two the kernel needs no register spills and is 6 % slower (per 16 1080p
+// frames 3.02 ms against 2.85); fetching a step ahead of the one in hand (twice the registers for what is fetched)
+// measured 3.5-3.9 ms at four and at three waves per SIMD.
 constexpr int ROWS_IN_FLIGHT = 4;
 // The tensor exists in NCOPY copies, and a lane adds to copy (lane & 15).  The LDS takes a 64-bit atomic of a wave in
 // four passes of 16 consecutive lanes, and only lanes of one pass can collide: two of them on one address cost 12
@@ -59,13 +62,6 @@ __device__ __forceinline__ void clip_strip(double s, double is, bool flat, doubl
     hi = fmin(hi, fmax(j1, j2));
 }
 
-// Value of `v` in lane `src` (wave-uniform index) for every lane.
-__device__ __forceinline__ double lane_broadcast(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-
 // Contributions are accumulated as unsigned fixed point with LDS 64-bit integer atomics: integer sums do not depend
 // on the order of the additions, so every schedule of the kernel gives the same tensor.  The conversion costs
 // nothing: the two Gaussian weight factors carry powers of two that put magnitude = mag * w_row * w_col at
@@ -75,17 +71,39 @@ __device__ __forceinline__ double lane_broadcast(double v, int src) {
 // sample add up to n exactly.  A gradient magnitude is below 2^9 and k <= 43, so n < 2^52.
 constexpr int FX_ROW_EXP = -500;  // the row weight carries 2^-500 (still a normal number), the column weight the rest
 
+// A wave-uniform double that the vector unit computed, moved to scalar registers.
+__device__ __forceinline__ double uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 __device__ __forceinline__ double pow2(int e) { return __longlong_as_double((long long)(1023 + e) << 52); }
 
 struct DescShared {
-    double wtab[256];
     unsigned long long tensor[INNER * NCOPY];  // after the copies are summed, its first 2*INNER words hold the sums and their squares as doubles
+    double wtab[256];
     int idx;
 };
 
+// A wave sweeps KS window rows side by side, 64 / KS lanes on consecutive columns of each ("sub-rows"): the column
+// intervals of a rotated window are 0 to ~150 samples long, and a whole wave per row leaves a quarter of its lanes
+// past the interval's end (measured: 76 % of the lanes of all sweeps carried a sample).  A 64-bit LDS atomic costs the
+// same whatever the number of active lanes, so the stage's time follows the number of sweeps.
+constexpr int KS = 4, WL = 64 / KS;
+
+// Value of `my` in lane `first + (this lane's sub-row)`: KS wave-uniform reads and KS - 1 selects.
+__device__ __forceinline__ int pick_row(int my, int first, int q) {
+    int v = __builtin_amdgcn_readlane(my, first);
+#pragma unroll
+    for (int k = 1; k < KS; k++) {
+        const int u = __builtin_amdgcn_readlane(my, first + k);
+        v = q >= k ? u : v;
+    }
+    return v;
+}
+
 // COUNT = false is the descriptor kernel.  COUNT = true walks the same samples with the same tests but, instead of
 // scattering them, counts them: per frame the samples that contribute (non-zero gradient inside the rotated window)
-// and the LDS double atomics they would issue (two per cell corner that lies inside the 4x4 grid), into
+// and the LDS atomics they would issue (two per cell corner that lies inside the 4x4 grid), into
 // work[frame][0..1].  It exists so that the kernel's throughput can be stated in the unit that bounds it.
 template <bool COUNT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_descriptors(Pyramid p, const DevKeypoint *__restrict__ kps, int kp_cap,
@@ -94,25 +112,26 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 
                                                       unsigned long long *__restrict__ work) {
     constexpr int NT = NWAVES * 64;
     static_assert(NT >= INNER, "one thread per bin in the normalisation");
-    __shared__ DescShared sm;
+    // 1024-byte alignment: the byte offset of a cell then has bits 7..9 (the orientation bin) clear
+    __shared__ __attribute__((aligned(1024))) DescShared sm;
     const int f = blockIdx.y;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int q = lane / WL, cl = lane & (WL - 1);
     int n = counters[f].keypoints;
     if (n > kp_cap) n = kp_cap;
     unsigned n_samples = 0, n_atomics = 0;  // COUNT only; per lane, per keypoint (a window holds < 2^17 samples)
     // Keypoints are pulled from a per-frame cursor: window areas differ by a factor of 25 between keypoints, and a
     // fixed round-robin deal of keypoints to workgroups measured 4 % slower than the cursor's dynamic balance.
-    // The list is sorted by x across all octaves, so concurrent workgroups sample unrelated windows and every sample
-    // row is an L2 miss.  Processing the keypoints in (octave, layer, 128-pixel tile) order instead, one eighth of
-    // the order per XCD, was measured: L2 misses per 16 frames fell from 317 M to 144 M and the kernel took 14.65 ms
-    // per 64 frames against 14.27 ms (plus 0.19 ms for the ordering pass): the kernel waits for its LDS atomics,
-    // not for memory, so the list order stays.
+    // The list is sorted by x across all octaves, so concurrent workgroups sample unrelated windows.  Processing
+    // the keypoints in (octave, layer, 128-pixel tile) order instead, one eighth of the order per XCD, takes 40 % off
+    // the L2 misses and nothing off the time (measured twice, on two generations of this kernel): the kernel does
+    // not wait for memory bandwidth, so the list order stays.
     for (;;) {
         if (tid == 0) sm.idx = atomicAdd(&cursors[f], 1);
         for (int t = tid; t < INNER * NCOPY; t += NT) sm.tensor[t] = 0;
         __syncthreads();
-        const int it = sm.idx;
+        const int it = __builtin_amdgcn_readfirstlane(sm.idx);
         if (it >= n) break;
         const DevKeypoint kpt = kps[(size_t)f * kp_cap + it];
         int octave = kpt.octave & 255;           // sift.cpp:469
@@ -123,18 +142,21 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 
         const int width = p.w[po], height = p.h[po];
         // gradients of gauss_images[octave + 1][layer] (sift.cpp:476)
         const Grad *image = p.grad[po] + grad_off(p, po, f, layer);
-        const int pt_x = (int)round(scale * kpt.x);
-        const int pt_y = (int)round(scale * kpt.y);
-        const double angle = 360 - kpt.angle;
-        const double cosv = cos(((double)(angle)*PI) / 180);
-        const double sinv = sin(((double)(angle)*PI) / 180);
+        const int pt_x = __builtin_amdgcn_readfirstlane((int)round(scale * kpt.x));
+        const int pt_y = __builtin_amdgcn_readfirstlane((int)round(scale * kpt.y));
+        const double angle = uniform(360 - kpt.angle);
+        const double cosv = uniform(cos(((double)(angle)*PI) / 180));
+        const double sinv = uniform(sin(((double)(angle)*PI) / 180));
         const double weight_multiplier = -0.5 / ((0.5 * WINDOW_WIDTH) * (0.5 * WINDOW_WIDTH));
         const double bins_per_degree = DBINS * 1.0 / 360.0;
-        const double hist_width = SCALE_MULTIPLIER * 0.5 * scale * kpt.size;  // sift.cpp:491
-        const int half_width =
-            (int)fmin(round(hist_width * (WINDOW_WIDTH + 1) / sqrt(2.0)),
-                      sqrt((double)height * (double)height + (double)width * (double)width));  // sift.cpp:492-493
-        const double inv_hw = 1.0 / hist_width;
+        const double hist_width = uniform(SCALE_MULTIPLIER * 0.5 * scale * kpt.size);  // sift.cpp:491
+        // The size of a localised keypoint is 1.6 * 2^(layer + offset / 3) * 2^(octave + 1) with layer <= 3 and
+        // |offset| < 0.5 (sift.cpp:378), which makes hist_width at most 43.2 in any octave and the half width at most
+        // 153: the weight table below has 256 entries, and the bound is enforced rather than assumed.
+        const int half_width = __builtin_amdgcn_readfirstlane(
+            min(255, (int)fmin(round(hist_width * (WINDOW_WIDTH + 1) / sqrt(2.0)),
+                               sqrt((double)height * (double)height + (double)width * (double)width))));  // sift.cpp:492-493
+        const double inv_hw = uniform(1.0 / hist_width);
         const double wscale = weight_multiplier * inv_hw * inv_hw;
         // Fixed-point position: fewer than 2^lg samples of less than 2^9 each, so that no sum reaches 2^63.
         const unsigned long long area = (unsigned long long)(2 * (long long)half_width + 1) * (unsigned long long)(2 * (long long)half_width + 1);
@@ -142,139 +164,143 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 
         // table entries: exp(..) * 2^(k - 1074 - FX_ROW_EXP) (column weights); a row weight is a table entry times
         // 2^(FX_ROW_EXP - (k - 1074 - FX_ROW_EXP)) = exp(..) * 2^FX_ROW_EXP
         const double col_scale = pow2(fx_bits - 1074 - FX_ROW_EXP);
-        const double row_scale = pow2(FX_ROW_EXP), tab_to_row = pow2(2 * FX_ROW_EXP + 1074 - fx_bits);
-        const bool use_tab = half_width < 256;
-        if (use_tab)
-            for (int t = tid; t <= half_width; t += NT) sm.wtab[t] = exp(wscale * (double)(t * t)) * col_scale;
+        const double tab_to_row = pow2(2 * FX_ROW_EXP + 1074 - fx_bits);
+        for (int t = tid; t <= half_width; t += NT) sm.wtab[t] = exp(wscale * (double)(t * t)) * col_scale;
         __syncthreads();
         // bin_row = (sin*j + cos*i)/hist_width + 1.5 = su*j + Bu(i); bin_col = (sin*i - cos*j)/hist_width + 1.5
-        // = sv*j + Bv(i) (sift.cpp:497-501); a sample counts when both lie in (-1, 4) (sift.cpp:503).
-        const double su = sinv * inv_hw, sv = -cosv * inv_hw;
+        // = sv*j + Bv(i) (sift.cpp:497-501); a sample counts when both lie in (-1, 4) (sift.cpp:503).  The loop
+        // works with both bins plus one, in (0, 5): truncation is then the floor, and the cell index needs no sign.
+        const double su = uniform(sinv * inv_hw), sv = uniform(-cosv * inv_hw);
+        const double cu = uniform(cosv * inv_hw), cv = uniform(sinv * inv_hw);
         const bool flat_u = fabs(su) < 1e-12, flat_v = fabs(sv) < 1e-12;
-        const double isu = flat_u ? 0.0 : 1.0 / su, isv = flat_v ? 0.0 : 1.0 / sv;
-        const double half_bins = 0.5 * (WINDOW_WIDTH - 1);
-        const double ang_bins = angle * bins_per_degree;
-        unsigned long long *T = sm.tensor + (lane & (NCOPY - 1));
+        const double isu = uniform(flat_u ? 0.0 : 1.0 / su), isv = uniform(flat_v ? 0.0 : 1.0 / sv);
+        const double half_bins1 = 0.5 * (WINDOW_WIDTH - 1) + 1.0;
+        // orientation bin plus 16 (positive for every direction in [-180, 180] and every keypoint angle in [-360, 720])
+        const double ang_bins16 = uniform(16.0 - angle * bins_per_degree);
+        // byte offset of this lane's copy of cell (-1, -1): a sample's cell offset is added to it
+        const int lane_base = (int)offsetof(DescShared, tensor) + (lane & (NCOPY - 1)) * 8 - (WINDOW_WIDTH + 1) * (CS * 8);
         // image bounds on the column: 0 < pt_x + j < width - 1 (sift.cpp:506)
         const int jmin = max(-half_width, 1 - pt_x), jmax = min(half_width, width - 2 - pt_x);
-        // Each wave takes rows wv, wv+NWAVES, ...  Row set-up (column interval, bin offsets, row
-        // weight) is done for 64 rows at once, one row per lane, and handed to the whole wave
-        // through readlane; ROWS_IN_FLIGHT rows are then swept together so that their gradient
-        // loads are all issued before the first one is consumed.
+        // Each wave takes rows wv, wv+NWAVES, ...  Row set-up (column interval) is done for 64 rows at once, one row
+        // per lane, and handed to the lanes that sweep the row through readlane; ROWS_IN_FLIGHT * KS rows are then
+        // swept together so that their gradient loads are all issued before the first one is consumed.
         for (int ib = -half_width + wv; ib <= half_width; ib += NWAVES * 64) {
-            int my_jlo = 0, my_jhi = -1;
-            double my_Bu, my_Bv, my_wi = 0.0;
+            int my_jlo = 1 - pt_x, my_jhi = -pt_x;  // empty: its lanes read column 0
             {
                 const int i = ib + lane * NWAVES;
                 const int win_row = pt_y + i;
-                my_Bu = (cosv * i) * inv_hw + half_bins;
-                my_Bv = (sinv * i) * inv_hw + half_bins;
+                const double my_Bu = cu * (double)i + half_bins1;
+                const double my_Bv = cv * (double)i + half_bins1;
                 if (i <= half_width && win_row > 0 && win_row < height - 1) {  // sift.cpp:506 (rows)
                     double lo = jmin, hi = jmax;
-                    clip_strip(su, isu, flat_u, my_Bu, lo, hi);
-                    clip_strip(sv, isv, flat_v, my_Bv, lo, hi);
+                    clip_strip(su, isu, flat_u, my_Bu - 1.0, lo, hi);
+                    clip_strip(sv, isv, flat_v, my_Bv - 1.0, lo, hi);
                     if (hi >= lo - 2) {
                         my_jlo = max(jmin, (int)floor(lo) - 1);
                         my_jhi = min(jmax, (int)ceil(hi) + 1);
-                        // Tighten the estimate to the exact set { j : -1 < bin_row, bin_col < 4 } (sift.cpp:503), with
-                        // the expressions the samples use.  Each of the four conditions is monotone in j (products and
-                        // sums round monotonically), so the set is an interval and the sample loop needs no test.
+                        // Tighten the estimate to the exact set { j : 0 < bin_row + 1, bin_col + 1 < 5 } (sift.cpp:503), with
+                        // the expressions the samples use.  Each of the four conditions is monotone in j (a fused
+                        // multiply-add rounds monotonically), so the set is an interval and the sample loop needs no test.
                         auto inside = [&](int j) {
                             const double dj = (double)j;
-                            const double br = su * dj + my_Bu, bc = sv * dj + my_Bv;
-                            return br > -1 && bc > -1 && br < WINDOW_WIDTH && bc < WINDOW_WIDTH;
+                            const double br = __builtin_fma(su, dj, my_Bu), bc = __builtin_fma(sv, dj, my_Bv);
+                            return br > 0 && bc > 0 && br < WINDOW_WIDTH + 1 && bc < WINDOW_WIDTH + 1;
                         };
                         while (my_jlo <= my_jhi && !inside(my_jlo)) my_jlo++;
                         while (my_jhi >= my_jlo && !inside(my_jhi)) my_jhi--;
+                        if (my_jhi < my_jlo) my_jlo = 1 - pt_x, my_jhi = -pt_x;
                     }
-                    my_wi = use_tab ? sm.wtab[min(abs(i), 255)] * tab_to_row : exp(wscale * (double)(i * i)) * row_scale;
                 }
             }
-            for (int g0 = 0; g0 < 64 && ib + g0 * NWAVES <= half_width; g0 += ROWS_IN_FLIGHT) {
-                const int i0 = ib + g0 * NWAVES;
-                int jlo[ROWS_IN_FLIGHT], jhi[ROWS_IN_FLIGHT];
+            for (int g0 = 0; g0 < 64 && ib + g0 * NWAVES <= half_width; g0 += ROWS_IN_FLIGHT * KS) {
+                // per slot r, for the lane's sub-row: pt_x + column interval, first element of the row, bin offsets, row weight
+                int xlo[ROWS_IN_FLIGHT], xhi[ROWS_IN_FLIGHT], yyw[ROWS_IN_FLIGHT];
                 double Bu[ROWS_IN_FLIGHT], Bv[ROWS_IN_FLIGHT], wi[ROWS_IN_FLIGHT];
-                int longest = 0;
+                int longest = 0;  // wave-uniform: the longest interval of the group
 #pragma unroll
                 for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
-                    jlo[r] = __builtin_amdgcn_readlane(my_jlo, g0 + r);
-                    jhi[r] = __builtin_amdgcn_readlane(my_jhi, g0 + r);
-                    Bu[r] = lane_broadcast(my_Bu, g0 + r);
-                    Bv[r] = lane_broadcast(my_Bv, g0 + r);
-                    wi[r] = lane_broadcast(my_wi, g0 + r);
-                    longest = max(longest, jhi[r] - jlo[r] + 1);
+#pragma unroll
+                    for (int k = 0; k < KS; k++)
+                        longest = max(longest, __builtin_amdgcn_readlane(my_jhi, g0 + r * KS + k) -
+                                                   __builtin_amdgcn_readlane(my_jlo, g0 + r * KS + k) + 1);
+                    xlo[r] = pt_x + pick_row(my_jlo, g0 + r * KS, q);
+                    xhi[r] = pt_x + pick_row(my_jhi, g0 + r * KS, q);
+                    const int i = ib + (g0 + r * KS + q) * NWAVES;
+                    const double di = (double)i;
+                    Bu[r] = cu * di + half_bins1;  // the expressions of the set-up above
+                    Bv[r] = cv * di + half_bins1;
+                    wi[r] = sm.wtab[min(abs(i), 255)] * tab_to_row;
+                    yyw[r] = min(max(pt_y + i, 0), height - 1) * width;
                 }
-                for (int c = 0; c < longest; c += 64) {
-                    // Everything the four rows read (gradients from memory, column weights from the
-                    // LDS table) is requested here, before the first atomic of the group: an LDS read
+                for (int c = cl; c - cl < longest; c += WL) {
+                    // Everything the rows read (gradients from memory, column weights from the
+                    // LDS table) is requested here, before the first atomic of the step: an LDS read
                     // issued between atomics would have to wait for all of them.  The loads are
-                    // unconditional, at addresses clamped into the plane, so that all four are in
-                    // flight together; lanes outside their row's interval discard what they read.
+                    // unconditional, at addresses clamped into the row's interval, so that all are in
+                    // flight together; lanes outside the interval discard what they read.
                     Grad g[ROWS_IN_FLIGHT];
                     double wj[ROWS_IN_FLIGHT];
 #pragma unroll
                     for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
-                        const int j = jlo[r] + c + lane;
-                        const int yy = min(max(pt_y + i0 + r * NWAVES, 0), height - 1);
                         // lanes past the end of their row's interval re-read its last sample instead of the memory behind it
-                        const int xx = min(max(pt_x + min(j, jhi[r]), 0), width - 1);
-                        g[r] = image[(size_t)yy * width + xx];  // sift.cpp:507-510
-                        wj[r] = sm.wtab[min(abs(j), 255)];
+                        g[r] = image[(unsigned)(yyw[r] + min(xlo[r] + c, xhi[r]))];  // sift.cpp:507-510
+                        wj[r] = sm.wtab[min(abs(xlo[r] + c - pt_x), 255)];
                     }
                     // keep the compiler from sinking a load into the branch that consumes it
 #pragma unroll
                     for (int r = 0; r < ROWS_IN_FLIGHT; r++) asm volatile("" : "+v"(g[r].mag), "+v"(g[r].ori), "+v"(wj[r]));
 #pragma unroll
                     for (int r = 0; r < ROWS_IN_FLIGHT; r++) {
-                        const int j = jlo[r] + c + lane;
-                        if (j > jhi[r]) continue;
+                        const int x = xlo[r] + c, j = x - pt_x;
+                        // a zero gradient adds nothing to any bin
+                        if (x > xhi[r] || g[r].mag == 0.0) continue;
                         const double dj = (double)j;
-                        const double bin_row = su * dj + Bu[r];
-                        const double bin_col = sv * dj + Bv[r];
+                        const double bin_row = __builtin_fma(su, dj, Bu[r]);  // in (0, 5)
+                        const double bin_col = __builtin_fma(sv, dj, Bv[r]);
                         // Gaussian weight exp(-(i^2+j^2)/(8 w^2)) (sift.cpp:512-517) as a product of two table entries
-                        // a zero gradient adds +0.0 to eight bins, which leaves every one of them unchanged
-                        if (g[r].mag == 0.0) continue;
-                        const double wcol = use_tab ? wj[r] : exp(wscale * (double)(j * j)) * col_scale;
-                        const double magnitude = (g[r].mag * wi[r]) * wcol;                  // sift.cpp:518, as an integer * 2^-1074
-                        const double orientation = g[r].ori * bins_per_degree - ang_bins;  // sift.cpp:519
-                        const double fr = floor(bin_row), fc = floor(bin_col), fo = floor(orientation);
-                        const int row_bin = (int)fr, col_bin = (int)fc;
-                        const double row_pr = bin_row - fr, col_pr = bin_col - fc, ori_pr = orientation - fo;
-                        const int ob0 = ((int)fo & (DBINS - 1)) * OS, ob1 = (((int)fo + 1) & (DBINS - 1)) * OS;
+                        const double magnitude = (g[r].mag * wi[r]) * wj[r];                 // sift.cpp:518, as an integer * 2^-1074
+                        const double orientation = __builtin_fma(g[r].ori, bins_per_degree, ang_bins16);  // sift.cpp:519, plus 16
+                        const int row_bin = (int)bin_row, col_bin = (int)bin_col, ori_bin = (int)orientation;  // plus 1, 1, 16
+                        const double row_pr = __builtin_amdgcn_fract(bin_row), col_pr = __builtin_amdgcn_fract(bin_col);
+                        const double ori_pr = __builtin_amdgcn_fract(orientation);
                         // trilinear split (sift.cpp:527-551): each step peels the upper share off the lower one
                         const double m1 = magnitude * row_pr, m0 = magnitude - m1;
                         const double m01 = m0 * col_pr, m00 = m0 - m01;
                         const double m11 = m1 * col_pr, m10 = m1 - m11;
-                        // cell (row_bin + a, col_bin + b) of the inner 4x4 grid; the border ring is dropped
-                        unsigned long long *cell = T + (row_bin * RS + col_bin * CS);
-                        const bool r0 = (unsigned)row_bin < (unsigned)WINDOW_WIDTH;
-                        const bool r1 = (unsigned)(row_bin + 1) < (unsigned)WINDOW_WIDTH;
-                        const bool c0 = (unsigned)col_bin < (unsigned)WINDOW_WIDTH;
-                        const bool c1 = (unsigned)(col_bin + 1) < (unsigned)WINDOW_WIDTH;
+                        // cell (row_bin - 1 + a, col_bin - 1 + b) of the inner 4x4 grid; the border ring is dropped
+                        const bool r0 = (unsigned)(row_bin - 1) < (unsigned)WINDOW_WIDTH;
+                        const bool r1 = (unsigned)row_bin < (unsigned)WINDOW_WIDTH;
+                        const bool c0 = (unsigned)(col_bin - 1) < (unsigned)WINDOW_WIDTH;
+                        const bool c1 = (unsigned)col_bin < (unsigned)WINDOW_WIDTH;
                         if constexpr (COUNT) {
                             n_samples += 1;
                             n_atomics += 2 * (((int)r0 + (int)r1) * ((int)c0 + (int)c1));
                             continue;
                         }
+                        const int cell = ((row_bin * WINDOW_WIDTH + col_bin) << 10) + lane_base;  // CS * 8 = 1024 bytes per cell
+                        const int obits = ori_bin << 7;                                          // OS * 8 = 128 bytes per orientation bin
+                        char *const lds = reinterpret_cast<char *>(&sm);
+                        unsigned long long *const a0 = reinterpret_cast<unsigned long long *>(lds + (cell | (obits & 0x380)));
+                        unsigned long long *const a1 = reinterpret_cast<unsigned long long *>(lds + (cell | ((obits + 128) & 0x380)));
                         if (r0 && c0) {
                             const double hi = m00 * ori_pr;
-                            atomicAdd(cell + ob0, (unsigned long long)__double_as_longlong(m00 - hi));
-                            atomicAdd(cell + ob1, (unsigned long long)__double_as_longlong(hi));
+                            atomicAdd(a0, (unsigned long long)__double_as_longlong(m00 - hi));
+                            atomicAdd(a1, (unsigned long long)__double_as_longlong(hi));
                         }
                         if (r0 && c1) {
                             const double hi = m01 * ori_pr;
-                            atomicAdd(cell + CS + ob0, (unsigned long long)__double_as_longlong(m01 - hi));
-                            atomicAdd(cell + CS + ob1, (unsigned long long)__double_as_longlong(hi));
+                            atomicAdd(a0 + CS, (unsigned long long)__double_as_longlong(m01 - hi));
+                            atomicAdd(a1 + CS, (unsigned long long)__double_as_longlong(hi));
                         }
                         if (r1 && c0) {
                             const double hi = m10 * ori_pr;
-                            atomicAdd(cell + RS + ob0, (unsigned long long)__double_as_longlong(m10 - hi));
-                            atomicAdd(cell + RS + ob1, (unsigned long long)__double_as_longlong(hi));
+                            atomicAdd(a0 + RS, (unsigned long long)__double_as_longlong(m10 - hi));
+                            atomicAdd(a1 + RS, (unsigned long long)__double_as_longlong(hi));
                         }
                         if (r1 && c1) {
                             const double hi = m11 * ori_pr;
-                            atomicAdd(cell + RS + CS + ob0, (unsigned long long)__double_as_longlong(m11 - hi));
-                            atomicAdd(cell + RS + CS + ob1, (unsigned long long)__double_as_longlong(hi));
+                            atomicAdd(a0 + RS + CS, (unsigned long long)__double_as_longlong(m11 - hi));
+                            atomicAdd(a1 + RS + CS, (unsigned long long)__double_as_longlong(hi));
                         }
                     }
                 }
