@@ -73,6 +73,9 @@ int sift_ctx_synchronize(sift_ctx *ctx);
  * sift_extract_batch_u8; 0 restores the default, max(8192, pixels/16).  The reference's vectors (sift.hpp:93-94) grow without bound: when a frame
  * exceeds the capacity, sift_extract_* runs it again in a larger workspace, so this is a memory knob only. */
 int sift_ctx_set_single_image_capacity(sift_ctx *ctx, int max_keypoints);
+/* Diagnostic (no counterpart in the reference): how many times the extraction pipeline has been launched on this
+ * context, whatever entry point launched it; lets a test see how sift_extract_batch_u8 cut a run into launches. */
+int sift_ctx_pipeline_runs(sift_ctx *ctx, int64_t *runs);
 
 /* ---- geometry helpers (host only) ---------------------------------------- */
 /* octaves = round(log2(min(w,h))) on the input size (sift.cpp:36). */
@@ -226,8 +229,9 @@ int sift_match_min_dist_filter(const sift_knn2 *knn, int nq, int32_t *good_idx, 
  * over several GPUs without leaving the process: frames are independent (contiguous blocks of frames per GPU, no
  * collective), and the matcher's train set is cut into contiguous shards whose per-GPU top-2 results are exchanged
  * with RCCL and merged.  A group borrows its contexts, normally one per GPU; they must outlive it.  (Several
- * contexts of one GPU may share a group for sift_extract_batch_u8, which then splits the frames between them;
- * sift_knn2_sharded requires distinct GPUs.)
+ * contexts of one GPU may share a group: sift_extract_batch_u8 then splits the frames between them, and
+ * sift_knn2_sharded moves the records with device-to-device copies ordered by events instead of RCCL, which has
+ * one rank per GPU.)
  * Calls on a group must not overlap with other calls on its contexts. */
 typedef struct sift_group sift_group;
 int sift_group_create(sift_ctx *const *ctxs, int ngpu, sift_group **out);
@@ -262,8 +266,9 @@ int sift_frame_results_free(sift_frame_result *results, int n);
 
 /* sift_knn2_u8 with the train set sharded over the GPUs of the group (main.cpp:75 at a size one GPU should not
  * hold): GPU r searches train rows [bounds[r], bounds[r+1]) for all queries, the partial top-2 records (16 bytes per
- * query) of query slice s travel to GPU s (grouped ncclSend/ncclRecv), which merges them under (distance, index)
- * order and applies the ratio test.  Results are identical to sift_knn2_u8 whatever the number of GPUs. */
+ * query) of query slice s travel to GPU s (grouped ncclSend/ncclRecv; copies when members share a GPU), which
+ * merges them under (distance, index) order and applies the ratio test.  Results are identical to sift_knn2_u8
+ * whatever the number of members. */
 int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t, int nt, sift_knn2 *out, uint8_t *accept);
 
 /* ---- homography from matches ------------------------------------------------ */

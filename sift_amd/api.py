@@ -35,7 +35,7 @@ COUNTS_DTYPE = np.dtype([("candidates", "<i4"), ("oriented", "<i4"), ("keypoints
 
 # every symbol include/sift_amd.h declares
 EXPORTED_SYMBOLS = (
-    "sift_last_error", "sift_device_count", "sift_ctx_create", "sift_ctx_destroy", "sift_ctx_stream",
+    "sift_last_error", "sift_device_count", "sift_ctx_create", "sift_ctx_destroy", "sift_ctx_stream", "sift_ctx_pipeline_runs",
     "sift_ctx_synchronize", "sift_ctx_set_single_image_capacity", "sift_num_octaves", "sift_octave_dims", "sift_extract_gray8", "sift_extract_bgr8", "sift_extract_gray8_stages", "sift_base_image_gray8",
     "sift_result_free", "sift_result_get_f32", "sift_batch_create", "sift_batch_destroy",
     "sift_batch_frames_device_ptr", "sift_batch_set_external_frames", "sift_batch_upload_gray8", "sift_batch_upload_bgr8", "sift_batch_run",
@@ -118,6 +118,7 @@ def lib():
     L.sift_ctx_destroy.argtypes = [vp]
     L.sift_ctx_stream.argtypes = [vp, pvp]
     L.sift_ctx_synchronize.argtypes = [vp]
+    L.sift_ctx_pipeline_runs.argtypes = [vp, C.POINTER(C.c_int64)]
     L.sift_ctx_set_single_image_capacity.argtypes = [vp, ci]
     L.sift_num_octaves.argtypes = [ci, ci]
     L.sift_octave_dims.argtypes = [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
@@ -172,6 +173,12 @@ def _check(rc):
 
 
 # ---- host-only helpers ------------------------------------------------------
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().sift_device_count(C.byref(n)))
+    return n.value
+
 
 def num_octaves(w, h):
     return lib().sift_num_octaves(w, h)
@@ -247,6 +254,11 @@ class Context:
 
     def synchronize(self):
         _check(lib().sift_ctx_synchronize(self._h))
+
+    def pipeline_runs(self):
+        n = C.c_int64(0)
+        _check(lib().sift_ctx_pipeline_runs(self._h, C.byref(n)))
+        return n.value
 
     def set_single_image_capacity(self, max_keypoints):
         """Initial list capacity of extract() (0: default); extract() grows it when a frame needs more."""

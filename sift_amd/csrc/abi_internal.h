@@ -61,6 +61,7 @@ struct sift_ctx {
     size_t pinned_bytes = 0;
     sift_batch *cached = nullptr;  // workspace of the single-image calls
     int single_cap = 0;            // its initial per-frame list capacity (0: the batch default)
+    long long pipeline_runs = 0;   // launches of the extraction pipeline on this context (sift_ctx_pipeline_runs)
 };
 
 struct sift_batch {

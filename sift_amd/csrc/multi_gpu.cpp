@@ -8,10 +8,11 @@
 //    local top-2 with global train indices; then each GPU sends, for every query slice, its partial results to
 //    the GPU that owns the slice (grouped ncclSend/ncclRecv, 16 bytes per query per peer, over xGMI), which
 //    merges them under (distance, index) order and applies the ratio test.  The result does not depend on the
-//    number of GPUs.
+//    number of GPUs.  A group with two members on one GPU cannot use RCCL (one communicator rank per device):
+//    its slices travel as device-to-device copies on the sender's stream, ordered by events.
 //
-// RCCL is resolved at run time (dlopen of librccl.so.1) on the first sharded matcher call, so that the library
-// has no load-time dependency on it and shares whichever copy the process already holds.
+// RCCL is resolved at run time (dlopen of librccl.so.1) on the first sharded matcher call that needs it, so that
+// the library has no load-time dependency on it and shares whichever copy the process already holds.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -90,6 +91,7 @@ struct sift_group {
     std::vector<ncclComm_t> comms;
     std::vector<DevBuffers> knn;
     std::vector<Pipe> pipe;
+    std::vector<hipEvent_t> sent;  // copy transport: member r's slices have all been copied out
 };
 
 namespace {
@@ -134,6 +136,7 @@ struct ExtractJob {
     int lo, hi;  // this GPU's frames [lo, hi)
     sift_frame_result *results;
     bool ramp;   // the library chooses the launch sizes (the caller named none)
+    int launch;  // frames per launch: at most the workspace's capacity, which an earlier call may have left larger
 };
 
 // Results of chunk `c` (frames first .. first + m) to the host: counts, then keypoints and descriptors of every
@@ -232,7 +235,7 @@ std::vector<int> launch_sizes(int total, int cap, bool ramp) {
 int pipe_run(sift_ctx *ctx, Pipe &p, const ExtractJob &job) {
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t px = (size_t)p.w * p.h;
-    const std::vector<int> sizes = launch_sizes(job.hi - job.lo, p.chunk, job.ramp);
+    const std::vector<int> sizes = launch_sizes(job.hi - job.lo, std::min(job.launch, p.chunk), job.ramp);
     const int nchunks = (int)sizes.size();
     std::vector<int> firsts((size_t)nchunks);
     for (int k = 0, at = job.lo; k < nchunks; at += sizes[k], k++) firsts[k] = at;
@@ -332,6 +335,8 @@ int sift_group_destroy(sift_group *g) {
     }
     for (ncclComm_t c : g->comms)
         if (c) g->rccl.CommDestroy(c);
+    for (hipEvent_t e : g->sent)
+        if (e) hipEventDestroy(e);
     delete g;
     return SIFT_OK;
 }
@@ -370,7 +375,7 @@ int sift_extract_batch_u8(sift_group *g, const uint8_t *frames, int n, int w, in
         chunk = std::min(chunk, hi - lo);
         int e = pipe_prepare(g->ctx[r], g->pipe[r], w, h, std::max(chunk, g->pipe[r].w == w && g->pipe[r].h == h ? g->pipe[r].chunk : 0));
         if (!e) {
-            ExtractJob job{frames, row_stride, frame_stride, lo, hi, results, frames_per_launch <= 0};
+            ExtractJob job{frames, row_stride, frame_stride, lo, hi, results, frames_per_launch <= 0, chunk};
             e = pipe_run(g->ctx[r], g->pipe[r], job);
         }
         if (e) {
@@ -404,14 +409,23 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
     if (any_byte_above_127(q, (size_t)nq * 128)) return fail(SIFT_ERR_NOT_INTEGRAL, "query descriptor value above 127");
     if (any_byte_above_127(t, (size_t)nt * 128)) return fail(SIFT_ERR_NOT_INTEGRAL, "train descriptor value above 127");
     const int ngpu = (int)g->ctx.size();
-    // one communicator rank per GPU: members that share a GPU can split frames between them, not a train set
+    // RCCL wants one communicator rank per GPU: a group with members that share a GPU exchanges by copies instead
+    bool by_copies = false;
     for (int i = 0; i < ngpu; i++)
         for (int j = 0; j < i; j++)
-            if (g->ctx[j]->device == g->ctx[i]->device)
-                return fail(SIFT_ERR_INVALID, "sift_knn2_sharded needs every context of the group on a GPU of its own");
-    int rc = load_rccl(g->rccl);
-    if (rc) return rc;
-    if (g->comms.empty()) {
+            if (g->ctx[j]->device == g->ctx[i]->device) by_copies = true;
+    int rc = SIFT_OK;
+    if (by_copies) {
+        while ((int)g->sent.size() < ngpu) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipSetDevice(g->ctx[g->sent.size()]->device));
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            g->sent.push_back(ev);
+        }
+    } else if ((rc = load_rccl(g->rccl))) {
+        return rc;
+    }
+    if (!by_copies && g->comms.empty()) {
         std::vector<int> devs;
         for (sift_ctx *c : g->ctx) devs.push_back(c->device);
         g->comms.assign((size_t)ngpu, nullptr);
@@ -488,18 +502,33 @@ int sift_knn2_sharded(sift_group *g, const uint8_t *q, int nq, const uint8_t *t,
         for (int r = 0; r < ngpu; r++)
             if (frc[r]) return fail(frc[r], "GPU " + std::to_string(g->ctx[r]->device) + ": " + fmsg[r]);
     }
-    // 2. slice s of every GPU's partial results goes to GPU s
-    ncclResult_t e = g->rccl.GroupStart();
-    for (int r = 0; r < ngpu && e == ncclSuccess; r++) {
-        for (int s = 0; s < ngpu && e == ncclSuccess; s++) {
-            e = g->rccl.Send(P[r].part + (size_t)s * slice * rec, (size_t)slice * rec, ncclChar, s, g->comms[r], g->ctx[r]->stream);
-            if (e == ncclSuccess)
-                e = g->rccl.Recv(P[r].recv + (size_t)s * slice * rec, (size_t)slice * rec, ncclChar, s, g->comms[r], g->ctx[r]->stream);
+    // 2. slice s of every GPU's partial results goes to GPU s, which files it under the sender's index
+    if (by_copies) {
+        for (int r = 0; r < ngpu; r++) {
+            HIP_TRY(hipSetDevice(g->ctx[r]->device));
+            for (int s = 0; s < ngpu; s++)
+                HIP_TRY(hipMemcpyPeerAsync(P[s].recv + (size_t)r * slice * rec, g->ctx[s]->device, P[r].part + (size_t)s * slice * rec,
+                                           g->ctx[r]->device, (size_t)slice * rec, g->ctx[r]->stream));
+            HIP_TRY(hipEventRecord(g->sent[r], g->ctx[r]->stream));
         }
+        for (int s = 0; s < ngpu; s++) {
+            HIP_TRY(hipSetDevice(g->ctx[s]->device));
+            for (int r = 0; r < ngpu; r++)
+                if (r != s) HIP_TRY(hipStreamWaitEvent(g->ctx[s]->stream, g->sent[r], 0));
+        }
+    } else {
+        ncclResult_t e = g->rccl.GroupStart();
+        for (int r = 0; r < ngpu && e == ncclSuccess; r++) {
+            for (int s = 0; s < ngpu && e == ncclSuccess; s++) {
+                e = g->rccl.Send(P[r].part + (size_t)s * slice * rec, (size_t)slice * rec, ncclChar, s, g->comms[r], g->ctx[r]->stream);
+                if (e == ncclSuccess)
+                    e = g->rccl.Recv(P[r].recv + (size_t)s * slice * rec, (size_t)slice * rec, ncclChar, s, g->comms[r], g->ctx[r]->stream);
+            }
+        }
+        const ncclResult_t e2 = g->rccl.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) return fail(SIFT_ERR_HIP, std::string("RCCL exchange: ") + g->rccl.GetErrorString(e));
     }
-    const ncclResult_t e2 = g->rccl.GroupEnd();
-    if (e == ncclSuccess) e = e2;
-    if (e != ncclSuccess) return fail(SIFT_ERR_HIP, std::string("RCCL exchange: ") + g->rccl.GetErrorString(e));
     // 3. merge on the owner of each slice, results down
     for (int r = 0; r < ngpu; r++) {
         sift_ctx *c = g->ctx[r];

@@ -410,6 +410,7 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_e
     sift_ctx *ctx = b->ctx;
     hipStream_t st = ctx->stream;
     HIP_TRY(hipSetDevice(ctx->device));
+    ctx->pipeline_runs++;
     StageTimer tm{b, times != nullptr, 0, {}, st};
     HIP_TRY(hipMemsetAsync(b->d_counters, 0, (size_t)n * sizeof(FrameCounters), st));
     HIP_TRY(hipMemsetAsync(b->d_cursors, 0, 3 * (size_t)b->max_frames * sizeof(int32_t), st));
@@ -514,6 +515,12 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_e
 }
 
 extern "C" {
+
+int sift_ctx_pipeline_runs(sift_ctx *ctx, int64_t *runs) {
+    if (!ctx || !runs) return fail(SIFT_ERR_INVALID, "NULL argument");
+    *runs = ctx->pipeline_runs;
+    return SIFT_OK;
+}
 
 int sift_batch_run(sift_batch *b, int n_frames) {
     if (!b) return fail(SIFT_ERR_INVALID, "batch is NULL");

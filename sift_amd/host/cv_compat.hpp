@@ -61,9 +61,18 @@ struct BlockCache {
     std::vector<Block> blocks;
     size_t held = 0;
     static constexpr size_t kMinBytes = (size_t)1 << 20, kMaxHeld = (size_t)512 << 20;
+    // Never destroyed: a matrix with static storage may give its block back after every other static object of
+    // the program is gone.
     static BlockCache &get() {
-        static BlockCache c;
-        return c;
+        static BlockCache *c = new BlockCache;
+        return *c;
+    }
+    // frees the held blocks (a long-lived process that has finished with large images)
+    void trim() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Block &b : blocks) delete[] b.p;
+        blocks.clear();
+        held = 0;
     }
     unsigned char *take(size_t bytes, size_t *got) {
         if (bytes >= kMinBytes) {
@@ -94,11 +103,11 @@ struct BlockCache {
         }
         delete[] p;
     }
-    ~BlockCache() {
-        for (const Block &b : blocks) delete[] b.p;
-    }
 };
 }  // namespace detail
+
+// Releases the matrix blocks kept for reuse (no counterpart in OpenCV).
+inline void trimMatCache() { detail::BlockCache::get().trim(); }
 
 // Dense 2-D matrix with reference-counted storage (the subset of cv::Mat used
 // around sift_handler: construction, at<>, ptr<>, clone, release, size, type).

@@ -27,6 +27,57 @@ def test_sharded_matcher_equals_the_single_context_one(sift_lib, ctx, group, ora
         assert np.array_equal(got["i2"], i2) and np.array_equal(got["d2"], d2) and np.array_equal(gacc, oacc)
 
 
+@pytest.mark.parametrize("members", [2, 3, 8])
+def test_sharded_matcher_with_several_members_on_one_gpu(sift_lib, ctx, oracle, members):
+    """More than one member: train shards, per-member feed threads, slice offsets on the send side, sender-order
+    receive, merge of `members` parts on every slice owner, per-owner download.  The members share the only GPU of
+    this box, so the slices travel as device-to-device copies; query counts that are not a multiple of the slice,
+    fewer train rows than members, fewer queries than members."""
+    others = [sift_lib.Context(0) for _ in range(members - 1)]
+    g = sift_lib.Group([ctx] + others)
+    try:
+        for nq, nt in [(1001, 20000), (members - 1, 977), (5, max(1, members - 2)), (64 * members + 1, 4096), (3, 0)]:
+            t = sift_lib.synth_descriptors(5, nt)
+            q = sift_lib.synth_queries(6, t, nq) if nt else np.zeros((nq, 128), np.uint8)
+            want, wacc = ctx.knn2(q, t)
+            for _ in range(2):  # the second call reuses the group's buffers and events
+                got, gacc = g.knn2(q, t)
+                assert np.array_equal(got, want) and np.array_equal(gacc, wacc)
+            if nt:
+                i1, d1, i2, d2, oacc = oracle.knn2_u8(q, t, threads=16)
+                assert np.array_equal(got["i1"], i1) and np.array_equal(got["d1"], d1)
+                assert np.array_equal(got["i2"], i2) and np.array_equal(got["d2"], d2) and np.array_equal(gacc, oacc)
+    finally:
+        g.close()
+        for o in others:
+            o.close()
+
+
+def test_groups_over_all_gpus_of_the_box(sift_lib, ctx, oracle):
+    """One context per GPU (RCCL transport for the matcher, one pipeline thread per GPU for the frames)."""
+    ngpu = min(sift_lib.device_count(), 4)
+    if ngpu < 2:
+        pytest.skip("needs at least two GPUs")
+    ctxs = [sift_lib.Context(i) for i in range(ngpu)]
+    g = sift_lib.Group(ctxs)
+    try:
+        for nq, nt in [(1001, 20000), (ngpu - 1, 977), (5, ngpu - 1)]:
+            t = sift_lib.synth_descriptors(5, nt)
+            q = sift_lib.synth_queries(6, t, nq)
+            want, wacc = ctx.knn2(q, t)
+            got, gacc = g.knn2(q, t)
+            assert np.array_equal(got, want) and np.array_equal(gacc, wacc)
+        w, h, n = 320, 240, 2 * ngpu + 1
+        frames = np.stack([sift_lib.synth_dead_leaves(7, i, w, h) for i in range(n)])
+        want = [ctx.extract(f) for f in frames]
+        for (kp, desc, _), (wkp, wdesc, _) in zip(g.extract_batch(frames, 2), want):
+            assert np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
+    finally:
+        g.close()
+        for c in ctxs:
+            c.close()
+
+
 def test_sharded_matcher_rejects_bytes_above_127(sift_lib, group):
     with pytest.raises(sift_lib.SiftError) as e:
         group.knn2(np.full((4, 128), 128, np.uint8), np.zeros((4, 128), np.uint8))
@@ -59,8 +110,7 @@ def test_batch_extraction_from_host_frames_equals_single_calls(sift_lib, ctx, gr
 
 def test_frames_split_over_two_members_driven_by_two_host_threads(sift_lib, ctx):
     """Two contexts in one group (both on the only GPU of this box): the frames are cut into two contiguous blocks,
-    each driven by its own host thread and pipeline, and every result lands at its frame's index.  The matcher
-    refuses such a group: its exchange needs one communicator rank per GPU."""
+    each driven by its own host thread and pipeline, and every result lands at its frame's index."""
     w, h, n = 320, 240, 9
     frames = np.stack([sift_lib.synth_dead_leaves(7, i, w, h) for i in range(n)])
     want = [ctx.extract(f) for f in frames]
@@ -74,8 +124,6 @@ def test_frames_split_over_two_members_driven_by_two_host_threads(sift_lib, ctx)
                 assert np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
         got = g.extract_batch(frames[:1], 4)               # fewer frames than members: one of them gets none
         assert np.array_equal(got[0][0], want[0][0])
-        with pytest.raises(sift_lib.SiftError):
-            g.knn2(np.zeros((4, 128), np.uint8), np.zeros((4, 128), np.uint8))
         with pytest.raises(sift_lib.SiftError):
             sift_lib.Group([ctx, ctx])
     finally:
@@ -94,6 +142,24 @@ def test_library_chosen_launch_sizes_cover_every_frame_once(sift_lib, ctx):
         for count in (n, 17, 16, 5):
             got = g.extract_batch(frames[:count], 0)
             assert len(got) == count
+            for (kp, desc, _), (wkp, wdesc, _) in zip(got, want):
+                assert np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
+    finally:
+        g.close()
+
+
+def test_a_smaller_launch_size_is_honoured_on_a_reused_group(sift_lib, ctx):
+    """The group keeps the larger workspace of an earlier call, but launches must follow the size the caller names
+    now: with frames_per_launch = 2 after a call with 8, seven frames take four launches, not one."""
+    w, h, n = 160, 120, 7
+    frames = np.stack([sift_lib.synth_dead_leaves(11, i, w, h) for i in range(n)])
+    want = [ctx.extract(f) for f in frames]
+    g = sift_lib.Group([ctx])
+    try:
+        for per_launch, launches in ((8, 1), (2, 4), (0, 1)):
+            before = ctx.pipeline_runs()
+            got = g.extract_batch(frames, per_launch)
+            assert ctx.pipeline_runs() - before == launches
             for (kp, desc, _), (wkp, wdesc, _) in zip(got, want):
                 assert np.array_equal(kp, wkp) and np.array_equal(desc, wdesc.astype(np.uint8))
     finally:
