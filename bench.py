@@ -15,7 +15,15 @@ dominant pyramid kernel measured with HIP events on the engine's own stream,
 and a bound + fraction for every other heavy kernel; per-stage device times;
 host-frames-in / host-results-out throughput; the matcher on the per-GPU share
 of the 1 M x 10 M configuration (search + merge + ratio test) with its MFMA
-fraction; and the CPU oracle timed on bounded samples of both workloads.
+fraction; the CPU oracle timed on bounded samples of both workloads; and, at
+N = 1, a `configs` block with the 3840x2160 batch and the single 2048x1080
+frame of the other benchmark configurations.
+
+Launched under torchrun (WORLD_SIZE set) every rank drives one GPU and the
+matcher's exchange is torch.distributed's all-to-all.  Launched as one plain
+process with --gpus N > 1, that process drives all N GPUs itself through the C
+group (sift_group_*): resident batches on every GPU for `value`, then
+sift_extract_batch_u8 and sift_knn2_sharded over the group (`c_group`).
 """
 import argparse
 import hashlib
@@ -31,9 +39,9 @@ sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak
 MFMA_I8_PEAK_TFLOPS = 5000.0  # dense int8 MFMA peak = 2x the 2.5 PF bf16 dense peak
-# ds_add_f64 retires 64 lanes per 8 cycles per CU when no two lanes collide (scripts/ubench/lds_atomic.hip):
-# 256 CUs x 8 lanes/clk x 2.4 GHz
-LDS_F64_ATOMIC_PEAK_GOPS = 256 * 8 * 2.4
+# ds_add_u64 retires one wave instruction (up to 64 lanes) per 7.2 clocks per CU when no two lanes of a 16-lane
+# pass collide (scripts/ubench/lds_atomic3.hip): 256 CUs x 64 / 7.2 lanes/clk x 2.4 GHz
+LDS_U64_ATOMIC_PEAK_GOPS = 256 * 64 / 7.2 * 2.4
 
 
 def source_hash():
@@ -52,6 +60,147 @@ def source_hash():
 def pyramid_geometry(w, h):
     import sift_amd as S
     return [S.octave_dims(w, h, o) for o in range(S.num_octaves(w, h))]
+
+
+def kernel_report(prof, W, H, B, traffic, work=None):
+    """roofline / pyramid / kernels blocks from one profiled pass (per-stage device times) of B WxH frames."""
+    dims = pyramid_geometry(W, H)
+    P = sum(w * h for w, h in dims)
+    P0 = dims[0][0] * dims[0][1]
+    P_scanned = sum(w * h for w, h in dims if w > 10 and h > 10)   # octaves with a non-empty scan range
+    total_ms = sum(v["ms"] for v in prof.values())
+    rep = {"stages_per_batch": {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "share": round(v["ms"] / total_ms, 4)}
+                                for k, v in prof.items() if v["launches"]}}
+    # Dominant pyramid kernel: the blur level with the largest device time.  Algorithmic bytes of one blur level
+    # over all octaves, as the reference formulates the work (GaussianBlur, sift.cpp:150, then subtract,
+    # sift.cpp:173): read G[j-1], write G[j], write D[j-1] = 3 x 8 B per pixel.  This engine never stores D (its
+    # two readers subtract in registers), so the bytes it has to MOVE are 2 x 8 B per pixel; that figure is
+    # reported beside the algorithmic one as `moved`.
+    blur = {k: v for k, v in prof.items() if k.startswith("blur_l")}
+    dom = max(blur, key=lambda k: blur[k]["ms"])
+    lv = blur[dom]
+    bytes_per_launch = 3 * 8 * P * B / lv["launches"]
+    moved_per_launch = 2 * 8 * P * B / lv["launches"]
+    avg_ms = lv["ms"] / lv["launches"]
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    moved = moved_per_launch / (avg_ms * 1e-3) / 1e9
+    taps = {"blur_l1": 11, "blur_l2": 13, "blur_l3": 17, "blur_l4": 21, "blur_l5": 27}[dom]
+    rep["roofline"] = {"bound": "hbm", "kernel": "k_blur_march<%d> (%d taps)" % (taps // 2, taps),
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": traffic.get(dom),   # mean HBM bytes per launch, like the algorithmic figure
+                       "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                       "launches_per_batch": lv["launches"],
+                       "moved": {"bytes_per_launch": moved_per_launch, "achieved": moved, "frac": moved / HBM_PEAK_GBS,
+                                 "note": "bytes this kernel has to move: the difference-of-Gaussians level is not stored"}}
+    pyr_ms = prof["base"]["ms"] + sum(v["ms"] for v in blur.values())
+    pyr_bytes = (W * H + 8 * P0 + 15 * 8 * P) * B
+    pyr_moved = (W * H + 8 * P0 + 10 * 8 * P) * B
+    rep["pyramid"] = {"ms_per_batch": pyr_ms, "algorithmic_GBs": pyr_bytes / (pyr_ms * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "moved_GBs": pyr_moved / (pyr_ms * 1e-3) / 1e9,
+                      "moved_frac_of_hbm_peak": pyr_moved / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "per_level_moved_frac": {k: round(2 * 8 * P * B / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                               for k, v in sorted(blur.items())}}
+    # every other heavy kernel: what bounds it and how close it runs to that bound
+    kernels = {}
+    ex = prof["extrema"]
+    ex_bytes = (6 * 8 + 3 * 16) * P_scanned * B      # six Gaussian levels read, three gradient planes written
+    kernels["extrema_gradients"] = {
+        "kernel": "k_extrema_grad", "bound": "hbm", "ms_per_batch": ex["ms"],
+        "algorithmic_bytes_per_batch": ex_bytes, "achieved": ex_bytes / (ex["ms"] * 1e-3) / 1e9, "unit": "GB/s",
+        "peak": HBM_PEAK_GBS, "frac": ex_bytes / (ex["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": traffic["k_extrema_grad"] * ex["launches"] if "k_extrema_grad" in traffic else None}
+    if work is not None:
+        dsc = prof["descriptor"]
+        upd = float(work[:, 1].sum())
+        kernels["descriptor"] = {
+            "kernel": "k_descriptors", "bound": "vector ALU issue beside the LDS atomic pipe", "ms_per_batch": dsc["ms"],
+            "window_samples_per_batch": float(work[:, 0].sum()), "histogram_updates_per_batch": upd,
+            "achieved": upd / (dsc["ms"] * 1e-3) / 1e9, "unit": "G ds_add_u64 lanes/s",
+            "peak": LDS_U64_ATOMIC_PEAK_GOPS, "frac": upd / (dsc["ms"] * 1e-3) / 1e9 / LDS_U64_ATOMIC_PEAK_GOPS,
+            "note": "peak = conflict-free ds_add_u64 rate with every lane active; by counters (profiles/) the vector "
+                    "ALUs are busy 58 % and the LDS 34 % of the kernel's cycles",
+            "traffic": traffic.get("k_descriptors")}
+    base = prof["base"]
+    base_bytes = (W * H + 8 * P0) * B
+    kernels["base"] = {"kernel": "k_base_march<5>", "bound": "hbm (write-only stream)", "ms_per_batch": base["ms"],
+                       "achieved": base_bytes / (base["ms"] * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                       "frac": base_bytes / (base["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get("base")}
+    rep["kernels"] = kernels
+    return rep
+
+
+def config_4k(S, torch, ctx, frames_per_step, steps):
+    """BASELINE config 4: 3840x2160 dead-leaves frames (seed 3), 11 octaves, 7680x4320 base."""
+    W, H, B = 3840, 2160, frames_per_step
+    host = np.empty((B, H, W), np.uint8)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as ex:
+        list(ex.map(lambda i: host.__setitem__(i, S.synth_dead_leaves(3, i, W, H)), range(B)))
+    pool = torch.from_numpy(host).cuda()
+    del host
+    batch = ctx.batch(W, H, B)
+    batch.set_external_frames(pool.data_ptr())
+    batch.run(B)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run(B)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    kp = float(batch.counts(B)["keypoints"].mean())
+    prof = None
+    for _ in range(2):
+        prof = batch.run_profiled(B)
+    rep = kernel_report(prof, W, H, B, {})
+    batch.close()
+    del pool
+    torch.cuda.empty_cache()
+    out = {"workload": "%d synthetic 3840x2160 dead-leaves frames (seed 3) per step, resident in HBM, full exec()" % B,
+           "frames_per_s": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "frames_per_step": B, "octaves": S.num_octaves(W, H), "keypoints_per_frame_mean": kp}
+    out.update(rep)
+    return out
+
+
+def config_single_frame(S, ctx, with_cpu):
+    """BASELINE config 2: the reference's res/2k.png is absent from its checkout; one 2048x1080 dead-leaves frame
+    (seed 2) stands in for it.  The whole pipeline on one frame, host buffer in, host keypoints and descriptors out."""
+    W, H = 2048, 1080
+    frame = S.synth_dead_leaves(2, 0, W, H)
+    for _ in range(3):
+        kps, desc, info = ctx.extract(frame)
+    times = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        ctx.extract(frame)
+        times.append(time.perf_counter() - t0)
+    _, _, ms = ctx.extract_stages(frame)
+    names = ["gen_gaussian_images", "gen_dog_images", "gen_scale_space_extrema", "clean_keypoints", "get_descriptors"]
+    out = {"workload": "one 2048x1080 dead-leaves frame (seed 2) standing in for the reference's absent res/2k.png: "
+                       "sift_extract_gray8, host frame in, host keypoints + descriptors out",
+           "host_to_host_ms_median": 1e3 * float(np.median(times)), "host_to_host_ms_min": 1e3 * float(np.min(times)),
+           "calls": len(times), "keypoints": int(info["keypoints"]), "candidates": int(info["candidates"]),
+           "stage_ms": {k: round(v, 4) for k, v in zip(names, ms)},
+           "stage_note": "device time between events at the reference's TIMEIT boundaries (sift.cpp:71-92) in the "
+                         "three-stream schedule of a single frame: levels 4-5 of an octave run beside the next "
+                         "octave's levels 1-3, so the first two boundaries are approximate; gen_dog_images is 0 "
+                         "(no such pass)"}
+    if with_cpu:
+        from oracle import oracle as O
+        cores = min(16, os.cpu_count() or 1)
+        o = O.OracleSift(frame)
+        t0 = time.perf_counter()
+        o.exec(threads=cores, blur_threads=cores)
+        dtc = time.perf_counter() - t0
+        n_cpu = len(o.keypoints())
+        stage = {k: round(v, 4) for k, v in o.timings.items()}
+        o.close()
+        out["cpu_baseline"] = {"value": dtc * 1e3, "unit": "ms per frame", "cores": cores, "kind": "port",
+                               "sample": "the same frame through the CPU oracle, all stages", "stage_seconds": stage,
+                               "keypoints": n_cpu, "gpu_keypoint_count_equal": bool(n_cpu == int(info["keypoints"]))}
+    return out
 
 
 def main():
@@ -75,6 +224,11 @@ def main():
     ap.add_argument("--cpu-knn-seconds", type=float, default=10.0)
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e-frames", type=int, default=256)
+    ap.add_argument("--no-configs", action="store_true", help="skip the 3840x2160 and single-frame legs")
+    ap.add_argument("--frames-4k", type=int, default=16)
+    ap.add_argument("--steps-4k", type=int, default=3)
+    ap.add_argument("--share-device", action="store_true",
+                    help="single-process --gpus N: put every member on GPU 0 (rehearsal of the group path on a one-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -94,34 +248,46 @@ def main():
 
     import sift_amd as S
 
+    # one plain process asked for several GPUs: it drives them all (the C group); under torchrun a rank drives one
+    members = args.gpus if (world == 1 and "WORLD_SIZE" not in os.environ and args.gpus > 1) else 1
+    devices = [0 if args.share_device else d for d in range(members)] if members > 1 else [local_rank]
+    if members > 1 and not args.share_device and S.device_count() < members:
+        raise SystemExit("--gpus %d in one process needs that many GPUs (%d visible)" % (members, S.device_count()))
+    parts = world * members   # GPUs (or members) over which the frames are sharded
+
     W, H, B = args.width, args.height, args.batch
-    nstreams = max(1, args.streams)
+    nstreams = max(1, args.streams) if members == 1 else 1
     if B % nstreams:
         raise SystemExit("--batch must be a multiple of --streams")
     Bs = B // nstreams
-    ctxs = [S.Context(local_rank) for _ in range(nstreams)]
+    ctxs = [S.Context(d) for d in devices for _ in range(nstreams)]
     batches = [c.batch(W, H, Bs) for c in ctxs]
     ctx, batch = ctxs[0], batches[0]
 
     # ---- synthetic frames, resident in HBM before the timed region -----------
     npool = max(1, args.pool)
-    host = np.empty((npool * B, H, W), np.uint8)
+    host = np.empty((members, npool * B, H, W), np.uint8)
 
-    def make_frame(k):
+    def make_frame(mk):
+        m, k = mk
         p, i = divmod(k, B)
-        host[k] = S.synth_dead_leaves(1, (p * world + rank) * B + i, W, H)
+        host[m, k] = S.synth_dead_leaves(1, (p * parts + rank * members + m) * B + i, W, H)
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 1) // max(1, world)))) as ex:
-        list(ex.map(make_frame, range(npool * B)))  # the generator is a reentrant C function (GIL released)
-    pool = torch.from_numpy(host).cuda()
-    torch.cuda.synchronize()
+        list(ex.map(make_frame, [(m, k) for m in range(members) for k in range(npool * B)]))  # reentrant C generator (GIL released)
+    pools = [torch.from_numpy(host[m]).to("cuda:%d" % devices[m]) for m in range(members)]
+    pool = pools[0]
+    host = host[0]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
 
     def run_step(step):
         p = step % npool
         for k, bt in enumerate(batches):
-            bt.set_external_frames(pool.data_ptr() + (p * B + k * Bs) * H * W)
-            bt.run(Bs)
+            m, sub = divmod(k, nstreams)
+            bt.set_external_frames(pools[m].data_ptr() + (p * B + sub * Bs) * H * W)
+            bt.run(Bs)   # enqueues and returns: one host thread keeps every GPU fed
 
     def sync_all():
         for c in ctxs:
@@ -129,7 +295,8 @@ def main():
 
     def barrier():
         sync_all()
-        torch.cuda.synchronize()
+        for d in set(devices):
+            torch.cuda.synchronize(d)
         if dist is not None:
             dist.barrier()
 
@@ -140,26 +307,65 @@ def main():
     for s in range(args.steps):
         run_step(args.warmup + s)
     sync_all()
-    torch.cuda.synchronize()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kp_mean = float(np.mean([bt.counts(Bs)["keypoints"].mean() for bt in batches]))
-    frames_total = world * args.steps * B
+    frames_total = parts * args.steps * B
     fps = frames_total / elapsed
 
     out = {
         "metric": "1080p frames/sec SIFT extract + 128-D desc pairs/sec KNN; % HBM/MFMA peak",
-        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": fps, "unit": "frames/s", "n_gpus": parts, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "batch of synthetic %dx%d dead-leaves frames (seed 1), image-sharded, "
                                "full exec(): pyramid, extrema + gradients, localise + orient, clean, descriptors" % (W, H),
                    "frames_per_gpu_per_step": B, "streams_per_gpu": nstreams, "distinct_batches_in_hbm": npool,
-                   "keypoints_per_frame_mean": kp_mean},
+                   "keypoints_per_frame_mean": kp_mean,
+                   "driver": ("one process per GPU (torchrun)" if world > 1 else
+                              "one process driving %d GPUs through the C group%s" % (members, " (all on GPU 0)" if args.share_device else "")
+                              if members > 1 else "one process, one GPU")},
     }
+
+    # ---- one process, several GPUs: the C group's two entry points over all members ----------
+    if members > 1:
+        for bt in batches[1:]:
+            bt.close()
+        del batches[1:]
+        grp = S.Group(ctxs)
+        cg = {"members": members, "devices": devices}
+        if not args.no_e2e:
+            nf = members * max(B, args.e2e_frames // B * B)
+            e2e_host = np.concatenate([host] * ((nf + host.shape[0] - 1) // host.shape[0]))[:nf]
+            grp.extract_batch_raw(e2e_host[:members * B], B)       # workspaces, page-locked buffers
+            t1 = time.perf_counter()
+            total_kp = grp.extract_batch_raw(e2e_host, B)
+            dt = time.perf_counter() - t1
+            cg["extract_batch"] = {"frames": nf, "frames_per_s": nf / dt, "keypoints": total_kp,
+                                   "what": "sift_extract_batch_u8 over the group: contiguous blocks of host frames per "
+                                           "member, a host thread and a double-buffered pipeline each, no collective"}
+            del e2e_host
+        if not args.no_knn:
+            nq, nt = args.knn_queries, args.knn_train * members
+            tr = S.synth_descriptors(5, nt)
+            qq = S.synth_queries(6, tr, nq)
+            grp.knn2(qq[:4096], tr[:65536])
+            t1 = time.perf_counter()
+            knn, acc = grp.knn2(qq, tr)
+            dt = time.perf_counter() - t1
+            ok = bool((knn["d1"] <= knn["d2"]).all() and (knn["i1"] >= 0).all() and (knn["i1"] < nt).all())
+            cg["knn2_sharded"] = {"queries": nq, "train_total": nt, "ms": dt * 1e3, "pairs_per_s": nq * nt / dt,
+                                  "accepted": int(acc.sum()), "sane": ok,
+                                  "what": "sift_knn2_sharded: host operands in, host results out (uploads included), "
+                                          "train rows sharded over the members, 16 B per query per peer exchanged, merge"}
+            del tr, qq
+        grp.close()
+        out["c_group"] = cg
 
     # ---- sharded matcher: every rank holds knn_train rows of the train set and all queries;
     # local top-2, one all-to-all of 16 B per query per peer, merge on the owner of each slice
@@ -198,6 +404,8 @@ def main():
     if rank == 0:
         # ---- per-kernel device time (HIP events on the engine's stream) ---------
         # (one context, one full-size batch, launches serialised by the event pairs)
+        for bt in batches[1:]:
+            bt.close()
         del batches[1:]
         if Bs != B:
             batches[0].close()
@@ -206,14 +414,6 @@ def main():
         prof = None
         for _ in range(3):
             prof = batch.run_profiled(B)
-        dims = pyramid_geometry(W, H)
-        P = sum(w * h for w, h in dims)
-        P0 = dims[0][0] * dims[0][1]
-        P_scanned = sum(w * h for w, h in dims if w > 10 and h > 10)   # octaves with a non-empty scan range
-        total_ms = sum(v["ms"] for v in prof.values())
-        stages = {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
-                      "share": round(v["ms"] / total_ms, 4)} for k, v in prof.items() if v["launches"]}
-        out["stages_per_batch"] = stages
 
         traffic = {}
         tpath = os.path.join(HERE, "profiles", "traffic.json")
@@ -226,69 +426,12 @@ def main():
                                if not k.startswith("_") and not k.endswith("_detail")}
             except Exception:
                 traffic = {}
-
-        # Dominant pyramid kernel: the blur level with the largest device time.  Algorithmic bytes of one blur level
-        # over all octaves, as the reference formulates the work (GaussianBlur, sift.cpp:150, then subtract,
-        # sift.cpp:173): read G[j-1], write G[j], write D[j-1] = 3 x 8 B per pixel.  This engine never stores D (its
-        # two readers subtract in registers), so the bytes it has to MOVE are 2 x 8 B per pixel; that figure is
-        # reported beside the algorithmic one as `moved`.
-        blur = {k: v for k, v in prof.items() if k.startswith("blur_l")}
-        dom = max(blur, key=lambda k: blur[k]["ms"])
-        lv = blur[dom]
-        bytes_per_launch = 3 * 8 * P * B / lv["launches"]
-        moved_per_launch = 2 * 8 * P * B / lv["launches"]
-        avg_ms = lv["ms"] / lv["launches"]
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        moved = moved_per_launch / (avg_ms * 1e-3) / 1e9
-        taps = {"blur_l1": 11, "blur_l2": 13, "blur_l3": 17, "blur_l4": 21, "blur_l5": 27}[dom]
-        out["roofline"] = {"bound": "hbm", "kernel": "k_blur_march<%d> (%d taps)" % (taps // 2, taps),
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": traffic.get(dom),   # mean HBM bytes per launch, like the algorithmic figure
-                           "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "launches_per_batch": lv["launches"],
-                           "moved": {"bytes_per_launch": moved_per_launch, "achieved": moved, "frac": moved / HBM_PEAK_GBS,
-                                     "note": "bytes this kernel has to move: the difference-of-Gaussians level is not stored"}}
-        pyr_ms = prof["base"]["ms"] + sum(v["ms"] for v in blur.values())
-        pyr_bytes = (W * H + 8 * P0 + 15 * 8 * P) * B
-        pyr_moved = (W * H + 8 * P0 + 10 * 8 * P) * B
-        out["pyramid"] = {"ms_per_batch": pyr_ms, "algorithmic_GBs": pyr_bytes / (pyr_ms * 1e-3) / 1e9,
-                          "frac_of_hbm_peak": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "moved_GBs": pyr_moved / (pyr_ms * 1e-3) / 1e9,
-                          "moved_frac_of_hbm_peak": pyr_moved / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "per_level_moved_frac": {k: round(2 * 8 * P * B / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                                   for k, v in sorted(blur.items())}}
-
-        # every other heavy kernel: what bounds it and how close it runs to that bound
-        kernels = {}
-        ex = prof["extrema"]
-        ex_bytes = (6 * 8 + 3 * 16) * P_scanned * B      # six Gaussian levels read, three gradient planes written
-        kernels["extrema_gradients"] = {
-            "kernel": "k_extrema_grad", "bound": "hbm", "ms_per_batch": ex["ms"],
-            "algorithmic_bytes_per_batch": ex_bytes, "achieved": ex_bytes / (ex["ms"] * 1e-3) / 1e9, "unit": "GB/s",
-            "peak": HBM_PEAK_GBS, "frac": ex_bytes / (ex["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": traffic["k_extrema_grad"] * ex["launches"] if "k_extrema_grad" in traffic else None}
-        work = batch.descriptor_work(B)
-        dsc = prof["descriptor"]
-        upd = float(work[:, 1].sum())
-        kernels["descriptor"] = {
-            "kernel": "k_descriptors", "bound": "lds-atomic", "ms_per_batch": dsc["ms"],
-            "window_samples_per_batch": float(work[:, 0].sum()), "histogram_updates_per_batch": upd,
-            "achieved": upd / (dsc["ms"] * 1e-3) / 1e9, "unit": "G ds_add_f64 lanes/s",
-            "peak": LDS_F64_ATOMIC_PEAK_GOPS, "frac": upd / (dsc["ms"] * 1e-3) / 1e9 / LDS_F64_ATOMIC_PEAK_GOPS,
-            "note": "LDS busy 80 % of the kernel's cycles by counters (profiles/); peak = conflict-free ds_add_f64 rate",
-            "traffic": traffic.get("k_descriptors")}
-        base = prof["base"]
-        base_bytes = (W * H + 8 * P0) * B
-        kernels["base"] = {"kernel": "k_base_march<5>", "bound": "hbm (write-only stream)", "ms_per_batch": base["ms"],
-                           "achieved": base_bytes / (base["ms"] * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                           "frac": base_bytes / (base["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get("base")}
-        out["kernels"] = kernels
+        out.update(kernel_report(prof, W, H, B, traffic, batch.descriptor_work(B)))
+        batch.close()
+        batch = None
 
         # ---- host frames in -> host keypoints + descriptors out ------------------
         if not args.no_e2e:
-            batch.close()
-            batch = None
             g = S.Group([ctx])
             # the same frames per launch as the resident batches, so that every launch of the run has one shape
             nf = max(B, args.e2e_frames // B * B)
@@ -304,6 +447,14 @@ def main():
                                          "page-locked staging overlapped with the kernels of the neighbouring chunks" % B}
             del e2e_host
             g.close()
+
+        # ---- the other benchmark configurations (N = 1 only, like the CPU baseline) ----------
+        if not args.no_configs and parts == 1:
+            del pools[:]
+            pool = None
+            torch.cuda.empty_cache()
+            out["configs"] = {"3840x2160_batch": config_4k(S, torch, ctx, args.frames_4k, args.steps_4k),
+                              "single_2048x1080_frame": config_single_frame(S, ctx, not args.no_cpu)}
 
         # ---- matcher: pairs/s and MFMA fraction on the per-GPU share of 1 M x 10 M ------
         if not args.no_knn:
