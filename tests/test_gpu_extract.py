@@ -165,6 +165,28 @@ def test_batch_schedule_equals_latency_schedule(sift_lib, ctx):
             assert np.array_equal(desc, single[i][1].astype(np.uint8))
 
 
+@pytest.mark.parametrize("name", ["lenna", "lennarotated"])
+def test_all_three_launch_size_tiers_agree_on_the_photographs(ctx, golden, name):
+    """The per-keypoint kernels exist in three widths, chosen by the pixels of a launch (up to 1 M, up to 4 M, more):
+    the descriptor tensor is summed in integers, so its three variants agree by construction; the orientation
+    histogram is summed in doubles in a team order and a wave order.  One 512x512 photograph run alone, eight and
+    twenty at a time must give the same keypoints and descriptors, which are the oracle's."""
+    g = golden(name)
+    gray = g["gray"]
+    h, w = gray.shape
+    kp1, desc1, _ = ctx.extract(gray)
+    assert len(kp1) == len(g["keypoints"])
+    for n in (1, 8, 20):
+        b = ctx.batch(w, h, n)
+        for i in range(n):
+            b.upload(i, gray)
+        b.run(n)
+        for i in (0, n - 1):
+            kp, desc = b.download(i)
+            assert np.array_equal(kp, kp1) and np.array_equal(desc, desc1.astype(np.uint8))
+        b.close()
+
+
 def test_keypoints_are_sorted_and_unique_like_the_reference(ctx, golden):
     kp, _, _ = ctx.extract(golden("lenna")["gray"])
     # comparator of sift.cpp:204-213 (coordinates already halved, which preserves order)
