@@ -92,7 +92,11 @@ __device__ __forceinline__ double direction_degrees(double dy, double dx, const 
 // and right neighbours from the adjacent lanes, so there is no LDS staging of pixels and no barrier after the
 // table copy.  Tiles cover the whole image (the gradient planes need every pixel); the extremum test is
 // confined to the BORDER-inset rectangle the reference scans (sift.cpp:188, :233).
-constexpr int EX_TW = 62, EX_TH = 16;  // 8 and 32 rows per workgroup (2 and 8 per thread) are slower: 15.1 and 17.9 ms against 14.9
+// 8 and 32 rows per workgroup (2 and 8 per thread) are slower: 15.1 and 17.9 ms against 14.9; so is a wave that
+// marches down its 62 columns with rows y-1..y+1 in registers and one new row loaded per step (6 loads per pixel
+// instead of 9): 15.1-16.4 ms with one to three rows fetched ahead.  The kernel's vector ALUs are busy two thirds
+// of its time, and a marching wave has a quarter of the independent arithmetic per step to hide their latency with.
+constexpr int EX_TW = 62, EX_TH = 16;
 
 // max / min of finite doubles as the bare instruction.  fmax()/fmin() make the compiler quieten possible
 // signalling NaNs first (one extra v_max_f64 per operand that comes from memory or from a lane exchange),
