@@ -71,21 +71,35 @@ def kernel_report(prof, W, H, B, traffic, work=None):
     total_ms = sum(v["ms"] for v in prof.values())
     rep = {"stages_per_batch": {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "share": round(v["ms"] / total_ms, 4)}
                                 for k, v in prof.items() if v["launches"]}}
-    # Dominant pyramid kernel: the blur level with the largest device time.  Algorithmic bytes of one blur level
-    # over all octaves, as the reference formulates the work (GaussianBlur, sift.cpp:150, then subtract,
-    # sift.cpp:173): read G[j-1], write G[j], write D[j-1] = 3 x 8 B per pixel.  This engine never stores D (its
-    # two readers subtract in registers), so the bytes it has to MOVE are 2 x 8 B per pixel; that figure is
-    # reported beside the algorithmic one as `moved`.
-    blur = {k: v for k, v in prof.items() if k.startswith("blur_l")}
-    dom = max(blur, key=lambda k: blur[k]["ms"])
+    # Pyramid launches.  A blur level is one launch per octave (blur_l1..blur_l5); in the batch schedule levels 1 and 2
+    # of the large octaves are one launch that does not read level 1 back (blur_l12).  Algorithmic bytes of a blur
+    # level, as the reference formulates the work (GaussianBlur, sift.cpp:150, then subtract, sift.cpp:173): read
+    # G[j-1], write G[j], write D[j-1] = 3 x 8 B per pixel.  This engine never stores D (its two readers subtract in
+    # registers), so the bytes a level has to MOVE are 2 x 8 B per pixel, and 3 x 8 B for the two fused levels
+    # together; those figures are reported beside the algorithmic ones as `moved`.
+    blur = {k: v for k, v in prof.items() if k.startswith("blur_l") and v["launches"]}
+    n_pair = prof.get("blur_l12", {"launches": 0})["launches"]          # the largest octaves
+    P_pair = sum(w * h for w, h in dims[:n_pair])
+
+    def level_px(k):   # pixels a stage's launches cover, and the levels each of them produces
+        if k == "blur_l12":
+            return P_pair, 2
+        return (P - P_pair if k in ("blur_l1", "blur_l2") else P), 1
+
+    # Dominant pyramid kernel: the launch kind with the largest device time per pyramid level it produces.
+    dom = max(blur, key=lambda k: blur[k]["ms"] / level_px(k)[1])
     lv = blur[dom]
-    bytes_per_launch = 3 * 8 * P * B / lv["launches"]
-    moved_per_launch = 2 * 8 * P * B / lv["launches"]
+    px, nlev = level_px(dom)
+    bytes_per_launch = nlev * 3 * 8 * px * B / lv["launches"]
+    moved_per_launch = (nlev + 1) * 8 * px * B / lv["launches"]
     avg_ms = lv["ms"] / lv["launches"]
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     moved = moved_per_launch / (avg_ms * 1e-3) / 1e9
-    taps = {"blur_l1": 11, "blur_l2": 13, "blur_l3": 17, "blur_l4": 21, "blur_l5": 27}[dom]
-    rep["roofline"] = {"bound": "hbm", "kernel": "k_blur_march<%d> (%d taps)" % (taps // 2, taps),
+    kname = {"blur_l1": "k_blur_march<5> (11 taps)", "blur_l2": "k_blur_march<6> (13 taps)", "blur_l3": "k_blur_march<8> (17 taps)",
+             "blur_l4": "k_blur_march<10> (21 taps)", "blur_l5": "k_blur_march<13> (27 taps)",
+             "blur_l12": "k_blur_pair<5, 6> (11 + 13 taps)"}[dom]
+    rep["roofline"] = {"bound": "hbm", "kernel": kname,
+                       "selection": "the pyramid launch kind with the largest device time per level it produces",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS,
                        "traffic": traffic.get(dom),   # mean HBM bytes per launch, like the algorithmic figure
@@ -95,13 +109,14 @@ def kernel_report(prof, W, H, B, traffic, work=None):
                                  "note": "bytes this kernel has to move: the difference-of-Gaussians level is not stored"}}
     pyr_ms = prof["base"]["ms"] + sum(v["ms"] for v in blur.values())
     pyr_bytes = (W * H + 8 * P0 + 15 * 8 * P) * B
-    pyr_moved = (W * H + 8 * P0 + 10 * 8 * P) * B
+    pyr_moved = (W * H + 8 * P0 + 10 * 8 * P - 8 * P_pair) * B
     rep["pyramid"] = {"ms_per_batch": pyr_ms, "algorithmic_GBs": pyr_bytes / (pyr_ms * 1e-3) / 1e9,
                       "frac_of_hbm_peak": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "moved_bytes_per_frame": pyr_moved / B,
                       "moved_GBs": pyr_moved / (pyr_ms * 1e-3) / 1e9,
                       "moved_frac_of_hbm_peak": pyr_moved / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "per_level_moved_frac": {k: round(2 * 8 * P * B / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                               for k, v in sorted(blur.items())}}
+                      "per_level_moved_frac": {k: round((level_px(k)[1] + 1) * 8 * level_px(k)[0] * B / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                               for k, v in sorted(blur.items()) if level_px(k)[0] * 50 > P}}
     # every other heavy kernel: what bounds it and how close it runs to that bound
     kernels = {}
     ex = prof["extrema"]

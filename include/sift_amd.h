@@ -172,7 +172,8 @@ int sift_batch_get_oriented(sift_batch *b, int frame, int capacity, sift_keypoin
 #define SIFT_STAGE_DESCRIPTOR 9 /* get_descriptors (sift.cpp:450-584) */
 #define SIFT_STAGE_GRADIENT 10  /* per-pixel gradient magnitude/direction of levels 1..3, shared by the orientation
                                    and descriptor windows (sift.cpp:410-415, :507-510) */
-#define SIFT_STAGE_COUNT 11
+#define SIFT_STAGE_BLUR_L12 11 /* levels 1 and 2 of a large octave in one launch (the batch schedule) */
+#define SIFT_STAGE_COUNT 12
 typedef struct sift_stage_times {
     double ms[SIFT_STAGE_COUNT];    /* summed kernel time per stage */
     int32_t launches[SIFT_STAGE_COUNT];

@@ -17,7 +17,7 @@ for t in range(trials):
     b.set_external_frames(pool.data_ptr())
     for _ in range(3):
         prof = b.run_profiled(B)
-    print(t, ' '.join('%s %.3f' % (k, prof[k]['ms']) for k in ('base', 'blur_l1', 'blur_l2', 'blur_l3', 'blur_l4', 'blur_l5', 'extrema', 'gradient', 'localize_orient', 'descriptor')), flush=True)
+    print(t, ' '.join('%s %.3f' % (k, prof[k]['ms']) for k in ('base', 'blur_l12', 'blur_l1', 'blur_l2', 'blur_l3', 'blur_l4', 'blur_l5', 'extrema', 'localize_orient', 'descriptor')), flush=True)
     if len(sys.argv) > 3 and sys.argv[3] == 'keep':
         keep.append(b)
     else:

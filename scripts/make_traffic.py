@@ -45,7 +45,7 @@ res = {"_calibration": {"fetch_factor": fetch_factor, "write_factor": write_fact
        "_frames_per_launch": frames, "_source_hash": source_hash(),
        "_unit": "HBM bytes per launch (mean over the launches of two %d-frame 1080p batches)" % frames}
 names = {"k_blur_march<5>": "blur_l1", "k_blur_march<6>": "blur_l2", "k_blur_march<8>": "blur_l3",
-         "k_blur_march<10>": "blur_l4", "k_blur_march<13>": "blur_l5", "k_base_march<5>": "base",
+         "k_blur_march<10>": "blur_l4", "k_blur_pair<5, 6>": "blur_l12", "k_blur_march<13>": "blur_l5", "k_base_march<5>": "base",
          "k_descriptors<false, 2>": "k_descriptors", "k_orient<false>": "k_orient", "k_rank_sort<false>": "k_rank_sort"}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):

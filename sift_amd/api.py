@@ -24,7 +24,7 @@ LEVEL_GRAD_MAG = 2
 LEVEL_GRAD_DIR = 3
 
 STAGE_NAMES = ("base", "blur_l1", "blur_l2", "blur_l3", "blur_l4", "blur_l5", "extrema", "localize_orient", "clean",
-               "descriptor", "gradient")
+               "descriptor", "gradient", "blur_l12")
 
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -75,7 +75,7 @@ class _FrameResult(C.Structure):
 
 
 class _StageTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 11), ("launches", C.c_int32 * 11)]
+    _fields_ = [("ms", C.c_double * len(STAGE_NAMES)), ("launches", C.c_int32 * len(STAGE_NAMES))]
 
 
 _lib = None

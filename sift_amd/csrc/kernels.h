@@ -15,6 +15,10 @@ void launch_blur(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes
 // per frame (two planes and a quarter in LDS).
 constexpr int SMALL_OCTAVE_PIXELS = 8192;
 // First octave from which on every octave is that small (p.octaves if none is).
+// Levels 1 and 2 of an octave in one launch (the first level is not read back from memory), for octaves large enough
+// for it (blur_levels_1_2_pair) and the 11- and 13-tap filters.
+bool blur_levels_1_2_pair(const Pyramid &p, int oct, const int *lvl_ntaps);
+void launch_blur_levels_1_2(hipStream_t st, const Pyramid &p, int oct, int nframes, const Taps *lvl_taps);
 int first_small_octave(const Pyramid &p);
 // Levels 1..5 of the octaves o_first.. of every frame; level 0 of octave o_first must be in place.  False (and no
 // launch) if the tap counts are not the five the kernel is compiled for.

@@ -23,6 +23,8 @@
 // results are bit-identical to a scalar CPU evaluation of the same filter:
 // rows accumulate taps left to right, s = c0*v0; s += ct*vt; columns start at
 // the centre tap and add symmetric pairs, s = cR*vR; s += c(R+t)*(v(R+t)+v(R-t)).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -420,6 +422,271 @@ void launch_blur_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nfram
                        (size_t)IMAGES * plane, next_stride, strip_h, taps);
 }
 
+// ---- two consecutive blur levels in one launch ----
+//
+// The levels whose filters are short enough to leave the vector ALUs idle are bound by the bytes they move: level
+// j reads G[j-1] and writes G[j], level j+1 reads G[j] again.  Here one workgroup carries a strip through both
+// filters: the rows of G[j] it has just finished go to memory and, by way of an LDS tile, into the row pass and the
+// ring of the second filter, so G[j] is never read back.  The first filter works on a tile HB columns wider on
+// either side than the strip (the second filter's horizontal support) and RB rows longer at either end of the
+// strip.  Operation order per pixel is that of march(), so both levels come out bit-identical to it.
+//
+// Borders.  Rows of G[j] above and below the image are needed reflected: G[j](-k) = G[j](k).  The first filter
+// simply keeps marching over those virtual rows with reflected input rows: its column sum adds the symmetric
+// pairs c[R+t] * (v[+t] + v[-t]), reflection swaps the two operands of every pair, and a + b = b + a exactly, so
+// the virtual row IS the reflected row.  The row sum runs left to right and has no such symmetry, so columns of
+// G[j] left and right of the image are copied from their mirror columns inside the tile before the second filter
+// reads them.
+constexpr int PAIR_MCH = 16, PAIR_TW = 48;
+template <int RA, int RB>
+struct PairGeom {
+    static constexpr int TW = PAIR_TW;            // output columns of the second level per strip
+    static constexpr int HB = 8;                  // halo of the first level's tile on either side
+    static constexpr int WA = TW + 2 * HB;        // the first level's tile: whole waves of columns
+    static constexpr int MCH = PAIR_MCH;          // rows per step
+    static constexpr int CX = 4, CY = 4;          // consecutive outputs per thread in a row pass / a column pass
+    static constexpr int NTHREADS = MCH * (WA / CX);
+    static constexpr int COLS = WA + 2 * RA;      // input staging tile
+    static constexpr int PIN = COLS | 1;
+    static constexpr int RINGA = MCH + 2 * RA, PRA = WA + 1;
+    static constexpr int PTA = WA + 1;            // tile of first-level rows handed to the second filter
+    static constexpr int RINGB = MCH + 2 * RB, PRB = TW + 1;
+    // the tile of first-level rows takes the place of the input staging tile, which the first row pass has consumed
+    static constexpr size_t LDS_BYTES = ((size_t)MCH * PIN + (size_t)RINGA * PRA + (size_t)RINGB * PRB) * sizeof(double);
+    static_assert(PTA <= PIN &&  RB <= HB && WA % 64 == 0 && TW % CX == 0 && MCH % CY == 0 &&
+                      (NTHREADS / 64) == (WA / 64) * (MCH / CY) && NTHREADS <= 1024, "geometry");
+};
+
+// Row sum of CX consecutive outputs: output m = sum over t = 0..2R, in this order, of c[t] * p[m + t].  The window is
+// streamed through registers ECH elements at a time (see march()).
+template <int R, int CX>
+__device__ __forceinline__ void row_sums(const double *p, const Taps &taps, double (&acc)[CX]) {
+    constexpr int NEL = CX + 2 * R, ECH = 4, NCH = (NEL + ECH - 1) / ECH;
+    double buf[2][ECH];
+#pragma unroll
+    for (int u = 0; u < ECH; u++) buf[0][u] = p[u];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int u = 0; u < ECH; u++)
+                if ((c + 1) * ECH + u < NEL) buf[(c + 1) & 1][u] = p[(c + 1) * ECH + u];
+        }
+        stream_fence();
+#pragma unroll
+        for (int u = 0; u < ECH; u++) {
+            const int k = c * ECH + u;
+            if (k >= NEL) break;
+            const double vk = buf[c & 1][u];
+#pragma unroll
+            for (int m = 0; m < CX; m++) {
+                const int t = k - m;
+                if (t == 0) acc[m] = taps.c[0] * vk;
+                else if (t > 0 && t <= 2 * R) acc[m] += taps.c[t] * vk;
+            }
+        }
+        stream_fence();
+    }
+}
+
+// Column sum of CY consecutive output rows at ring column x: output m = c[R] * v[m+R] plus, for t = 1..R in this
+// order, c[R+t] * (v[m+R+t] + v[m+R-t]), v[k] = ring row (slot0 + k) mod RING (see march()).
+template <int R, int CY, int RING, int PR>
+__device__ __forceinline__ void column_sums(const double *ring, int slot0, int x, const Taps &taps, double (&acc)[CY]) {
+    auto ld = [&](int k) {
+        int sl = slot0 + k;
+        sl = sl >= RING ? sl - RING : sl;
+        return ring[sl * PR + x];
+    };
+    constexpr int TCH = 2, NTC = (R + TCH - 1) / TCH;
+    double hi_w[CY], lo_w[CY];
+    {
+        double cen[CY];
+#pragma unroll
+        for (int m = 0; m < CY; m++) cen[m] = ld(R + m);
+#pragma unroll
+        for (int m = 0; m < CY; m++) acc[m] = taps.c[R] * cen[m];
+#pragma unroll
+        for (int m = 0; m + 1 < CY; m++) hi_w[m] = cen[m + 1];
+        hi_w[CY - 1] = ld(R + CY);
+#pragma unroll
+        for (int m = 1; m < CY; m++) lo_w[m] = cen[m - 1];
+        lo_w[0] = ld(R - 1);
+    }
+    double fresh_hi[2][TCH], fresh_lo[2][TCH];
+#pragma unroll
+    for (int u = 0; u < TCH; u++) {
+        const int t = 1 + u;
+        if (t < R) {
+            fresh_hi[0][u] = ld(R + t + CY);
+            fresh_lo[0][u] = ld(R - t - 1);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NTC; c++) {
+        if (c + 1 < NTC) {
+#pragma unroll
+            for (int u = 0; u < TCH; u++) {
+                const int t = 1 + (c + 1) * TCH + u;
+                if (t < R) {
+                    fresh_hi[(c + 1) & 1][u] = ld(R + t + CY);
+                    fresh_lo[(c + 1) & 1][u] = ld(R - t - 1);
+                }
+            }
+        }
+        stream_fence();
+#pragma unroll
+        for (int u = 0; u < TCH; u++) {
+            const int t = 1 + c * TCH + u;
+            if (t > R) break;
+#pragma unroll
+            for (int m = 0; m < CY; m++) acc[m] += taps.c[R + t] * (hi_w[m] + lo_w[m]);
+            if (t < R) {
+#pragma unroll
+                for (int m = 0; m + 1 < CY; m++) hi_w[m] = hi_w[m + 1];
+                hi_w[CY - 1] = fresh_hi[c & 1][u];
+#pragma unroll
+                for (int m = CY - 1; m > 0; m--) lo_w[m] = lo_w[m - 1];
+                lo_w[0] = fresh_lo[c & 1][u];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < CY; m++) asm volatile("" : "+v"(acc[m]));
+        stream_fence();
+    }
+}
+
+// grid: (strips of TW columns, vertical segments, frames).  in -> outA (filter A) -> outB (filter B).
+template <int RA, int RB>
+__global__ __launch_bounds__(PAIR_MCH * ((PAIR_TW + 16) / 4)) void k_blur_pair(const double *__restrict__ in, double *__restrict__ outA,
+                                                            double *__restrict__ outB, int w, int h, size_t frame_stride,
+                                                            int strip_h, Taps tapsA, Taps tapsB) {
+    using G = PairGeom<RA, RB>;
+    constexpr int NTHREADS = G::NTHREADS, MCH = G::MCH, TW = G::TW, HB = G::HB, WA = G::WA;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *s_in = smem, *tileA = smem, *ringA = s_in + MCH * G::PIN, *ringB = ringA + G::RINGA * G::PRA;
+    const TileId tile = xcd_tile_id();
+    in += (size_t)tile.z * frame_stride;
+    outA += (size_t)tile.z * frame_stride;
+    outB += (size_t)tile.z * frame_stride;
+    const int tid = threadIdx.x;
+    const int tx0 = tile.x * TW, ax0 = tx0 - HB;  // first column of the strip / of the first level's tile
+    const int ys = tile.y * strip_h, ye = min(h, ys + strip_h);
+    const int nA = ye - ys + 2 * RB;              // first-level rows the strip needs: virtual rows ys - RB ..
+    const int nsteps = (ye - ys + 2 * RA + 2 * RB + MCH - 1) / MCH;
+    const bool edge_x = ax0 - RA < 0 || ax0 + WA + RA > w;  // uniform over the workgroup
+
+    // input staging: a thread owns one row of the MCH x COLS tile and every TPR-th column of it
+    constexpr int TPR = NTHREADS / MCH, NS = (G::COLS + TPR - 1) / TPR;
+    const int srow = tid / TPR, sc0 = tid % TPR;
+    double pf[NS];
+    auto fetch = [&](int s) {
+        int gy = ys - RB - RA + MCH * s + srow;
+        if ((unsigned)gy >= (unsigned)h) gy = reflect101(gy, h);
+        const double *row = in + (size_t)gy * w;
+        if (!edge_x) {
+            const int gx0 = ax0 - RA + sc0;
+#pragma unroll
+            for (int u = 0; u < NS; u++)
+                if ((u + 1) * TPR <= G::COLS || sc0 + TPR * u < G::COLS) pf[u] = row[gx0 + TPR * u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < NS; u++)
+                if ((u + 1) * TPR <= G::COLS || sc0 + TPR * u < G::COLS) pf[u] = row[reflect101(ax0 - RA + sc0 + TPR * u, w)];
+        }
+    };
+    const int row = tid & (MCH - 1), cx = tid / MCH;
+    // column passes: a wave is 64 columns of one group of CY rows
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = (wave % (WA / 64)) * 64 + (tid & 63), cy = wave / (WA / 64);
+    fetch(0);
+    for (int s = 0; s < nsteps; s++) {
+        {
+            double *q = s_in + srow * G::PIN + sc0;
+#pragma unroll
+            for (int u = 0; u < NS; u++)
+                if ((u + 1) * TPR <= G::COLS || sc0 + TPR * u < G::COLS) q[TPR * u] = pf[u];
+        }
+        __syncthreads();  // staging tile complete; the previous step is done with every ring and tile
+        if (s + 1 < nsteps) fetch(s + 1);
+        {   // filter A, row pass: input row (MCH s + row) of the strip into ring A
+            double acc[G::CX];
+            row_sums<RA, G::CX>(s_in + row * G::PIN + cx * G::CX, tapsA, acc);
+            double *q = ringA + ((MCH * s + row) % G::RINGA) * G::PRA + cx * G::CX;
+#pragma unroll
+            for (int m = 0; m < G::CX; m++) q[m] = acc[m];
+        }
+        __syncthreads();
+        // First-level rows finished by this step: j0 .. j0 + MCH - 1 (row j is virtual row ys - RB + j of that level).
+        const int j0 = MCH * s - 2 * RA;
+        {   // filter A, column pass: tile row cy*CY + m is first-level row j0 + cy*CY + m
+            const int jf = j0 + cy * G::CY;
+            if (jf + G::CY > 0 && jf < nA) {
+                double acc[G::CY];
+                column_sums<RA, G::CY, G::RINGA, G::PRA>(ringA, (jf + 8 * G::RINGA) % G::RINGA, x, tapsA, acc);
+                const int gx = ax0 + x;
+#pragma unroll
+                for (int m = 0; m < G::CY; m++) {
+                    tileA[(cy * G::CY + m) * G::PTA + x] = acc[m];
+                    const int y = ys - RB + jf + m;
+                    if (y >= ys && y < ye && x >= HB && x < HB + TW && gx < w) outA[(size_t)y * w + gx] = acc[m];
+                }
+            }
+        }
+        __syncthreads();
+        if (edge_x) {  // first-level columns outside the image are their mirror columns
+            for (int c = cx; c < WA; c += NTHREADS / MCH) {
+                const int gx = ax0 + c;
+                if ((unsigned)gx >= (unsigned)w) {
+                    const int m = reflect101(gx, w) - ax0;
+                    if ((unsigned)m < (unsigned)WA) tileA[row * G::PTA + c] = tileA[row * G::PTA + m];
+                }
+            }
+            __syncthreads();
+        }
+        {   // filter B, row pass: tile row `row` = first-level row j0 + row into ring B
+            const int j = j0 + row;
+            if (j >= 0 && j < nA && cx < TW / G::CX) {
+                double acc[G::CX];
+                row_sums<RB, G::CX>(tileA + row * G::PTA + (HB - RB) + cx * G::CX, tapsB, acc);
+                double *q = ringB + (j % G::RINGB) * G::PRB + cx * G::CX;
+#pragma unroll
+                for (int m = 0; m < G::CX; m++) q[m] = acc[m];
+            }
+        }
+        __syncthreads();
+        {   // filter B, column pass: output rows ys + (j0 - 2 RB + cy*CY + m)
+            const int b0 = j0 - 2 * RB + cy * G::CY;  // strip-relative output row of m = 0; its window starts at ring row b0
+            const int gx = tx0 + x;
+            if (b0 + G::CY > 0 && ys + b0 < ye && x < TW && gx < w) {
+                double acc[G::CY];
+                column_sums<RB, G::CY, G::RINGB, G::PRB>(ringB, (b0 + 8 * G::RINGB) % G::RINGB, x, tapsB, acc);
+#pragma unroll
+                for (int m = 0; m < G::CY; m++) {
+                    const int y = ys + b0 + m;
+                    if (y >= ys && y < ye) outB[(size_t)y * w + gx] = acc[m];
+                }
+            }
+        }
+    }
+}
+
+template <int RA, int RB>
+void launch_blur_pair_r(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes, const Taps &tapsA, const Taps &tapsB) {
+    using G = PairGeom<RA, RB>;
+    const int w = p.w[oct], h = p.h[oct];
+    const size_t plane = (size_t)w * h;
+    const int nx = (w + G::TW - 1) / G::TW;
+    int ny = (2048 + nx * nframes - 1) / (nx * nframes);
+    const int max_ny = (h + 127) / 128;  // a segment repeats 2 (RA + RB) rows of the first filter
+    ny = std::max(1, std::min(ny, max_ny));
+    int strip_h = ((h + ny - 1) / ny + G::MCH - 1) / G::MCH * G::MCH;
+    ny = (h + strip_h - 1) / strip_h;
+    hipLaunchKernelGGL((k_blur_pair<RA, RB>), dim3(nx, ny, nframes), dim3(G::NTHREADS), G::LDS_BYTES, st,
+                       p.gauss[oct] + (size_t)(lvl - 1) * plane, p.gauss[oct] + (size_t)lvl * plane,
+                       p.gauss[oct] + (size_t)(lvl + 1) * plane, w, h, (size_t)IMAGES * plane, strip_h, tapsA, tapsB);
+}
+
 // cvtColor(BGR2GRAY) on 8-bit data (sift.cpp:29): OpenCV 4.x integer formula
 // with 15-bit coefficients B 3735, G 19235, R 9798 and a rounding shift.
 __global__ void k_bgr_to_gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray, size_t n) {
@@ -549,6 +816,9 @@ int pyramid_init_attributes() {
     rc |= set_lds_attr<8>();
     rc |= set_lds_attr<10>();
     rc |= set_lds_attr<13>();
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blur_pair<5, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)PairGeom<5, 6>::LDS_BYTES) != hipSuccess)
+        rc = -1;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_base_march<5>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MarchGeom<5>::LDS_BYTES);
     if (e != hipSuccess) rc = -1;
@@ -587,6 +857,15 @@ void launch_blur(hipStream_t st, const Pyramid &p, int oct, int lvl, int nframes
         case 13: launch_blur_r<13>(st, p, oct, lvl, nframes, taps); break;
         default: break;  // rejected on the host before any launch
     }
+}
+
+bool blur_levels_1_2_pair(const Pyramid &p, int oct, const int *lvl_ntaps) {
+    // a narrow octave is mostly halo in 48-column strips, and its launches are short either way
+    return lvl_ntaps[1] == 11 && lvl_ntaps[2] == 13 && p.w[oct] >= 4 * PairGeom<5, 6>::TW && p.h[oct] >= 64;
+}
+
+void launch_blur_levels_1_2(hipStream_t st, const Pyramid &p, int oct, int nframes, const Taps *lvl_taps) {
+    launch_blur_pair_r<5, 6>(st, p, oct, 1, nframes, lvl_taps[1], lvl_taps[2]);
 }
 
 int first_small_octave(const Pyramid &p) {

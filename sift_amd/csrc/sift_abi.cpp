@@ -479,9 +479,17 @@ int sa::run_pipeline(sift_batch *b, int n, sift_stage_times *times, bool group_e
         }
     } else {
         TIMED(SIFT_STAGE_BASE, launch_base(st, frames, b->w, b->h, n, b->pyr, b->base_taps, b->base_ntaps));
-        for (int o = 0; o < b->pyr.octaves; o++)
-            for (int lvl = 1; lvl < IMAGES; lvl++)
+        for (int o = 0; o < b->pyr.octaves; o++) {
+            int lvl = 1;
+            // Levels 1 and 2 of a large octave are one launch that never reads level 1 back (0.33 ms of 4.68 per 64
+            // 1080p frames; the single-frame schedule keeps one launch per level: it is bound by launch latency).
+            if (blur_levels_1_2_pair(b->pyr, o, b->lvl_ntaps)) {
+                TIMED(SIFT_STAGE_BLUR_L12, launch_blur_levels_1_2(st, b->pyr, o, n, b->lvl_taps));
+                lvl = 3;
+            }
+            for (; lvl < IMAGES; lvl++)
                 TIMED(SIFT_STAGE_BLUR_L1 + lvl - 1, launch_blur(st, b->pyr, o, lvl, n, b->lvl_taps[lvl], b->lvl_ntaps[lvl]));
+        }
         if (group_events) HIP_TRY(hipEventRecord(ctx->group_ev[1], st));
         for (int o = 0; o < b->pyr.octaves; o++)
             if (b->pyr.grad[o])

@@ -106,6 +106,30 @@ def test_tiny_and_sliver_frames(sift_lib, ctx, oracle, w, h, seed):
     run_both(sift_lib, ctx, oracle, sift_lib.synth_dead_leaves(seed, 0, w, h))
 
 
+@pytest.mark.parametrize("w,h,n,seed", [(333, 205, 1, 41), (415, 301, 3, 42), (97, 640, 2, 43), (1920, 1080, 1, 44), (800, 600, 12, 45)])
+def test_batch_schedule_pyramid_against_oracle(sift_lib, ctx, oracle, w, h, n, seed):
+    """The batch schedule (taken by the profiled pass whatever the size, and by launches of more than 4 M pixels)
+    computes levels 1 and 2 of the large octaves in one launch that hands level 1 on through the LDS: strips of 48
+    columns that do not divide the width, octaves too narrow for it (which fall back to one launch per level),
+    one frame cut into vertical segments (1920x1080: seventeen of them) and many frames in one launch.  Every level
+    of every octave of the first and the last frame must equal the oracle's."""
+    frames = [sift_lib.synth_dead_leaves(seed, i, w, h) for i in range(n)]
+    b = ctx.batch(w, h, n)
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run_profiled(n)
+        for i in sorted({0, n - 1}):
+            o = oracle.OracleSift(frames[i]).exec(threads=16, blur_threads=16)
+            for oc in range(o.octaves):
+                for lvl in range(6):
+                    assert np.array_equal(b.level(i, oc, lvl, sift_lib.LEVEL_GAUSS), o.gauss(oc, lvl)), (i, oc, lvl)
+            assert np.array_equal(sorted_quads(b.candidates(i)), oracle_quads(o))
+            o.close()
+    finally:
+        b.close()
+
+
 def test_natural_crop_non_multiple_of_tile(sift_lib, ctx, oracle, lenna_bgr):
     gray = oracle.bgr_to_gray(lenna_bgr)[37:37 + 301, 50:50 + 415].copy()
     run_both(sift_lib, ctx, oracle, gray)
