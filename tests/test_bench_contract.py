@@ -1,4 +1,4 @@
-"""The bench line: the last recorded run (profiles/r2_bench.json, written by `python bench.py` on an MI355X)
+"""The bench line: the last recorded run (profiles/r3_bench.json, written by `python bench.py` on an MI355X)
 carries every field the measurement contract names, with consistent values."""
 import json
 import os
@@ -12,7 +12,7 @@ def load(name):
 
 
 def test_recorded_bench_line_has_the_contract_fields():
-    d = load("r2_bench.json")
+    d = load("r3_bench.json")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "frames/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -41,14 +41,24 @@ def test_recorded_bench_line_has_the_contract_fields():
     assert d["end_to_end"]["frames_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    # the other benchmark configurations ride in the same line
+    k4 = d["configs"]["3840x2160_batch"]
+    assert k4["octaves"] == 11 and k4["frames_per_s"] > 0 and 0 < k4["roofline"]["frac"] < 1
+    assert 0 < k4["pyramid"]["moved_frac_of_hbm_peak"] < k4["pyramid"]["frac_of_hbm_peak"] < 1
+    one = d["configs"]["single_2048x1080_frame"]
+    assert one["host_to_host_ms_median"] > 0 and len(one["stage_ms"]) == 5
+    oc = one["cpu_baseline"]
+    assert oc["cores"] >= 1 and oc["value"] > one["host_to_host_ms_median"] and oc["gpu_keypoint_count_equal"] is True
 
 
 def test_rocprof_summary_agrees_with_the_event_timing():
-    """profiles/r2_bench_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of the run that wrote
-    r2_bench_profiled.json: the dominant kernel's average duration must match the HIP-event figure."""
+    """profiles/r3_bench_main_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of the run that wrote
+    r3_bench_profiled_main.json (`bench.py --no-configs`: the default run without the legs of the other
+    configurations, whose launches of other shapes would enter the profiler's per-kernel average): the dominant
+    kernel's average duration must match the HIP-event figure."""
     import csv
-    d = load("r2_bench_profiled.json")
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv"))))
+    d = load("r3_bench_profiled_main.json")
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r3_bench_main_kernel_stats.csv"))))
     name = d["roofline"]["kernel"].split()[0]   # k_blur_march<13>
     hit = [r for r in rows if name in r["Name"]]
     assert len(hit) == 1
