@@ -359,7 +359,7 @@ def main():
             e2e_host = np.concatenate([host] * ((nf + host.shape[0] - 1) // host.shape[0]))[:nf]
             grp.extract_batch_raw(e2e_host[:members * B], B)       # workspaces, page-locked buffers
             t1 = time.perf_counter()
-            total_kp = grp.extract_batch_raw(e2e_host, B)
+            total_kp = grp.extract_batch_raw(e2e_host, -B)
             dt = time.perf_counter() - t1
             cg["extract_batch"] = {"frames": nf, "frames_per_s": nf / dt, "keypoints": total_kp,
                                    "what": "sift_extract_batch_u8 over the group: contiguous blocks of host frames per "
@@ -448,18 +448,19 @@ def main():
         # ---- host frames in -> host keypoints + descriptors out ------------------
         if not args.no_e2e:
             g = S.Group([ctx])
-            # the same frames per launch as the resident batches, so that every launch of the run has one shape
+            # launches of at most the resident batches' size, cut by the library: a quarter-size launch first and last
             nf = max(B, args.e2e_frames // B * B)
             e2e_host = np.concatenate([host] * ((nf + host.shape[0] - 1) // host.shape[0]))[:nf]
             g.extract_batch_raw(e2e_host[:2 * B], B)         # workspaces, page-locked buffers
             t1 = time.perf_counter()
-            total_kp = g.extract_batch_raw(e2e_host, B)
+            total_kp = g.extract_batch_raw(e2e_host, -B)
             dt = time.perf_counter() - t1
             out["end_to_end"] = {"frames": nf, "frames_per_s": nf / dt, "ms_per_frame": 1e3 * dt / nf,
                                  "keypoints": total_kp,
                                  "what": "sift_extract_batch_u8: pageable host frames in, host keypoints + 128-byte "
-                                         "descriptors out, %d frames per launch, uploads and downloads through "
-                                         "page-locked staging overlapped with the kernels of the neighbouring chunks" % B}
+                                         "descriptors out, at most %d frames per launch with a quarter-size launch first "
+                                         "and last, uploads and downloads through page-locked staging overlapped with "
+                                         "the kernels of the neighbouring chunks" % B}
             del e2e_host
             g.close()
 

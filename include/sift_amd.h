@@ -250,8 +250,8 @@ int sift_knn2_exchange_plan(int nq, int parts, int rank, int32_t *slice_len, int
  * frames + i*frame_stride with row_stride bytes per row: frames are dealt to the GPUs of the group in contiguous
  * blocks, and every GPU runs its block frames_per_launch frames at a time through two workspaces, so that
  * the upload of the next chunk and the download of the previous one overlap the kernels.  frames_per_launch <= 0
- * leaves the launch sizes to the library: at most 16 frames, with a quarter-size launch first and last (the GPU
- * starts sooner and the last download, which nothing overlaps, is shorter).  results[i] receives
+ * leaves the launch sizes to the library: at most -frames_per_launch frames (16 for 0), with a quarter-size launch
+ * first and last (the GPU starts sooner and the last download, which nothing overlaps, is shorter).  results[i] receives
  * frame i's keypoints (clean_keypoints order) and 128-byte descriptors in library-owned buffers released by
  * sift_frame_results_free.  A frame that exceeds the workspace's list capacity is run again on its own in a larger
  * one, as sift_extract_gray8 does. */

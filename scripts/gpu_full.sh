@@ -24,10 +24,11 @@ python scripts/make_traffic.py $O 64 > $O/traffic_summary.txt && cp profiles/tra
 tail -12 $O/traffic_summary.txt
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 bench.py > $O/bench_profiled.json 2> $O/bench_profiled.err || { tail -20 $O/bench_profiled.err; exit 1; }
 python scripts/bench_summary.py $O/bench_profiled.json
-# the same under the profiler without the legs of the other configurations: every launch of a kernel then has the
-# shape the roofline figure is quoted for, and the profiler's per-kernel average can be held against the event timing
+# the same under the profiler without the legs of the other configurations and without the host-to-host leg (whose
+# first and last launches are a quarter of the size): every launch of a kernel then has the shape the roofline figure
+# is quoted for, and the profiler's per-kernel average can be held against the event timing
 rm -rf $O/prof_bench_main
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench_main -o bench -- python3 bench.py --no-configs > $O/bench_profiled_main.json 2> $O/bench_profiled_main.err || { tail -20 $O/bench_profiled_main.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench_main -o bench -- python3 bench.py --no-configs --no-e2e > $O/bench_profiled_main.json 2> $O/bench_profiled_main.err || { tail -20 $O/bench_profiled_main.err; exit 1; }
 python scripts/bench_summary.py $O/bench_profiled_main.json
 timeout -k 10 300 python -u bench.py > $O/bench_plain.json 2> $O/bench_plain.err || { tail -20 $O/bench_plain.err; exit 1; }
 python scripts/bench_summary.py $O/bench_plain.json

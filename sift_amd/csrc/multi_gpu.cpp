@@ -371,7 +371,7 @@ int sift_extract_batch_u8(sift_group *g, const uint8_t *frames, int n, int w, in
     auto work = [&](int r) {
         const int lo = (int)bounds[r], hi = (int)bounds[r + 1];
         if (lo == hi) return;
-        int chunk = frames_per_launch > 0 ? frames_per_launch : 16;
+        int chunk = frames_per_launch > 0 ? frames_per_launch : frames_per_launch < 0 ? -frames_per_launch : 16;
         chunk = std::min(chunk, hi - lo);
         int e = pipe_prepare(g->ctx[r], g->pipe[r], w, h, std::max(chunk, g->pipe[r].w == w && g->pipe[r].h == h ? g->pipe[r].chunk : 0));
         if (!e) {

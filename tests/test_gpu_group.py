@@ -150,13 +150,14 @@ def test_library_chosen_launch_sizes_cover_every_frame_once(sift_lib, ctx):
 
 def test_a_smaller_launch_size_is_honoured_on_a_reused_group(sift_lib, ctx):
     """The group keeps the larger workspace of an earlier call, but launches must follow the size the caller names
-    now: with frames_per_launch = 2 after a call with 8, seven frames take four launches, not one."""
+    now: with frames_per_launch = 2 after a call with 8, seven frames take four launches, not one.  A negative size
+    is a cap on launches whose sizes the library chooses."""
     w, h, n = 160, 120, 7
     frames = np.stack([sift_lib.synth_dead_leaves(11, i, w, h) for i in range(n)])
     want = [ctx.extract(f) for f in frames]
     g = sift_lib.Group([ctx])
     try:
-        for per_launch, launches in ((8, 1), (2, 4), (0, 1)):
+        for per_launch, launches in ((8, 1), (2, 4), (0, 1), (-4, 4)):   # -4: at most 4, cut by the library: 1, 3, 2, 1
             before = ctx.pipeline_runs()
             got = g.extract_batch(frames, per_launch)
             assert ctx.pipeline_runs() - before == launches
