@@ -35,6 +35,19 @@ SA_HD double recip_refined(double d) {
     return r;
 }
 
+// A double constant held in scalar registers on the device.  A 64-bit literal cannot be an operand, and left to itself
+// the compiler moves the addend of every multiply-add of a polynomial into the destination vector registers first
+// (two moves per constant and evaluation); an opaque scalar pair makes it take the three-operand form instead.
+SA_HD double scalar_const(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    long long bits = __builtin_bit_cast(long long, c);
+    asm("" : "+s"(bits));
+    return __builtin_bit_cast(double, bits);
+#else
+    return c;
+#endif
+}
+
 // `knots` points at the 33 {hi, lo} pairs of SA_ATAN_KNOTS (any address space).
 SA_HD double atan2_fast(double y, double x, const double (*knots)[2]) {
     double ax = fabs(x), ay = fabs(y);
@@ -60,9 +73,9 @@ SA_HD double atan2_fast(double y, double x, const double (*knots)[2]) {
         u = fma(fma(-u, den, num), rd, u);
         const double s = u * u;
         double p = 1.0 / 9.0;
-        p = fma(p, s, -1.0 / 7.0);
-        p = fma(p, s, 1.0 / 5.0);
-        p = fma(p, s, -1.0 / 3.0);
+        p = fma(p, s, scalar_const(-1.0 / 7.0));
+        p = fma(p, s, scalar_const(1.0 / 5.0));
+        p = fma(p, s, scalar_const(-1.0 / 3.0));
         const double au = fma(u * s, p, u);
         r = knots[i][0] + (knots[i][1] + au);
     }

@@ -38,8 +38,9 @@ __device__ __forceinline__ int wave_append(bool flag, int32_t *counter) {
 template <bool from_left>
 __device__ __forceinline__ double neighbour_lane(double v) {
     constexpr int ctrl = from_left ? 0x138 : 0x130;  // DPP wave_shr:1 / wave_shl:1
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    // bound_ctrl: the end lane reads zero, so the destination needs no initial value (one move less per half)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
