@@ -5,10 +5,10 @@
 // Replaces scale_space_extrema_parallel::operator() and its helpers
 // (sift.cpp:227-448).  Floating-point operations are written in the order of a
 // scalar evaluation of those functions and contraction is off for this file,
-// so localisation is bit-reproducible against a CPU evaluation; each partial
-// orientation histogram is updated by lanes of a single wave only and the
-// partial histograms are combined in a fixed order, so it is reproducible run
-// to run.
+// so localisation is bit-reproducible against a CPU evaluation; the orientation
+// histogram is summed in fixed point, so it does not depend on the order of
+// its additions: it is the same run to run and whichever kernel variant the
+// launch size selects.
 #include "angle_table.h"
 #include "atan2_fast.h"
 #include "common.h"
@@ -431,7 +431,10 @@ __global__ __launch_bounds__(256) void k_localize(Pyramid p, const Candidate *__
 // weight exp(wf*(i^2+j^2)) is the product of two entries of a per-keypoint
 // table exp(wf*t^2).
 constexpr int OCOPIES = 16;
-constexpr int OSTRIDE = OCOPIES + 1;  // bins start one LDS bank pair apart
+// Word of (bin, copy) = bin * 16 + copy, copy = lane & 15: the LDS takes a 64-bit atomic in four passes of 16
+// consecutive lanes, whose copies all differ, so no two lanes of a pass share an address, and their banks
+// 2 * copy + 32 * (bin & 1) all differ too, whatever bins they hit.
+constexpr int OSTRIDE = OCOPIES;
 constexpr int OWAVES = 4;             // waves (= keypoints in flight) per workgroup
 constexpr int WTAB = 128;
 constexpr int OSAMP = 4;             // samples per lane per trip of the window loop (2 and 8 measure the same)
@@ -439,19 +442,23 @@ constexpr int OSAMP = 4;             // samples per lane per trip of the window 
 // TEAM = false: a wave per keypoint (launches with keypoints enough to keep every wave busy).  TEAM = true: the four
 // waves of a workgroup share a keypoint, each taking every fourth trip through the window with partial histograms
 // of its own, which wave 0 then adds up wave by wave; for one or a few frames, where the stage lasts as long as its
-// largest windows.  The two modes add the same terms in different orders.
+// largest windows.  The histogram is summed in fixed point (64-bit integer LDS atomics on contributions rounded to
+// multiples of 2^-k, k = 40 and more), so the two modes, which add the same terms in different orders, give the same
+// bins bit for bit, and so does every run.  The conversion is free: the two Gaussian weight factors carry 2^((k-1074)/2)
+// each, which puts magnitude * w_row * w_col at n * 2^-1074, where the bit pattern of a double is the integer n.
 template <bool TEAM>
 __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeypoint *__restrict__ localized,
                                                          int kp_cap, DevKeypoint *__restrict__ oriented,
                                                          FrameCounters *__restrict__ counters,
                                                          const int32_t *__restrict__ n_localized) {
-    __shared__ double s_hist[OWAVES][BINS * OSTRIDE];
+    __shared__ unsigned long long s_hist[OWAVES][BINS * OSTRIDE];
     __shared__ double s_hsum[OWAVES][BINS];
     __shared__ double s_smooth[OWAVES][BINS];
     __shared__ double s_wtab[OWAVES][WTAB];
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *hist = s_hist[wv], *hsum = s_hsum[TEAM ? 0 : wv], *smooth = s_smooth[TEAM ? 0 : wv], *wtab = s_wtab[TEAM ? 0 : wv];
+    unsigned long long *hist = s_hist[wv];
+    double *hsum = s_hsum[TEAM ? 0 : wv], *smooth = s_smooth[TEAM ? 0 : wv], *wtab = s_wtab[TEAM ? 0 : wv];
     int n = n_localized[f];
     if (n > kp_cap) n = kp_cap;
     // keypoints are dealt to the waves of the frame round-robin: a shared cursor would cost one
@@ -473,13 +480,19 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
         const double scale = SCALE_FACTOR * kpt.size / double(1 << (oct + 1));  // sift.cpp:401
         const int radius = (int)round(scale * RADIUS_FACTOR);
         const double weight_factor = -0.5 / (scale * scale);
-        for (int t = lane; t < BINS * OSTRIDE; t += 64) hist[t] = 0.0;
+        // fewer than 2^lg samples of less than 2^9 each (a gradient magnitude is at most 255 * sqrt(2)): no bin reaches
+        // 2^63; k even, so that each weight factor carries half of the scale
+        const unsigned long long area = (unsigned long long)(2 * (long long)radius + 1) * (unsigned long long)(2 * (long long)radius + 1);
+        const int fx_bits = min(42, 54 - (64 - __builtin_clzll(area))) & ~1;
+        const double half_scale = __longlong_as_double((long long)(1023 + (fx_bits - 1074) / 2) << 52);
+        const double unscale = __longlong_as_double((long long)(1023 - fx_bits) << 52);
+        for (int t = lane; t < BINS * OSTRIDE; t += 64) hist[t] = 0;
         const bool use_tab = radius < WTAB;
         if (use_tab) {
             if constexpr (TEAM) {
-                for (int t = threadIdx.x; t <= radius; t += 64 * OWAVES) wtab[t] = exp(weight_factor * (double)(t * t));
+                for (int t = threadIdx.x; t <= radius; t += 64 * OWAVES) wtab[t] = exp(weight_factor * (double)(t * t)) * half_scale;
             } else {
-                for (int t = lane; t <= radius; t += 64) wtab[t] = exp(weight_factor * (double)(t * t));
+                for (int t = lane; t <= radius; t += 64) wtab[t] = exp(weight_factor * (double)(t * t)) * half_scale;
             }
         }
         if constexpr (TEAM) __syncthreads(); else wave_sync();
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
                 rj = s0 - qi * n1;
             }
             Grad g[OSAMP];
-            double wgt[OSAMP];
+            double wrow[OSAMP], wcol[OSAMP];  // exp(-i^2 / 2 s^2) and exp(-j^2 / 2 s^2), each times 2^((k - 1074) / 2)
             bool ok[OSAMP];
 #pragma unroll
             for (int u = 0; u < OSAMP; u++) {
@@ -509,8 +522,13 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
                 ok[u] = s0 + 64 * u < total && y > 0 && y < h - 1 && x > 0 && x < w - 1;  // sift.cpp:407,409
                 const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
                 g[u] = L[(size_t)yc * w + xc];  // mag, direction (sift.cpp:410-415)
-                wgt[u] = use_tab ? wtab[min(abs(ii), WTAB - 1)] * wtab[min(abs(jj), WTAB - 1)]
-                                 : exp(weight_factor * (ii * ii + jj * jj));
+                if (use_tab) {
+                    wrow[u] = wtab[min(abs(ii), WTAB - 1)];
+                    wcol[u] = wtab[min(abs(jj), WTAB - 1)];
+                } else {
+                    wrow[u] = exp(weight_factor * (ii * ii + jj * jj)) * half_scale;
+                    wcol[u] = half_scale;
+                }
                 rj += r64;
                 qi += q64;
                 if (rj >= n1) {
@@ -524,7 +542,8 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
                 // ((int)round(ori*36/360) % 36 + 36) % 36 (sift.cpp:416); |ori| <= 180, so the rounded value lies in [-18, 18]
                 const int k = round_half_away(div_360(g[u].ori * BINS));
                 const int index = k < 0 ? k + BINS : k;
-                atomicAdd(&hist[index * OSTRIDE + copy], wgt[u] * g[u].mag);  // sift.cpp:417
+                // sift.cpp:417: the first product is an ordinary number, the second lands on the integer grid
+                atomicAdd(&hist[index * OSTRIDE + copy], (unsigned long long)__double_as_longlong((g[u].mag * wrow[u]) * wcol[u]));
             }
         }
         if constexpr (TEAM) __syncthreads(); else wave_sync();
@@ -533,16 +552,14 @@ __global__ __launch_bounds__(64 * OWAVES) void k_orient(Pyramid p, const DevKeyp
             continue;
         }
         if (lane < BINS) {
-            double t = 0.0;
+            unsigned long long t = 0;
 #pragma unroll
             for (int v = 0; v < (TEAM ? OWAVES : 1); v++) {
-                const double *hv = TEAM ? s_hist[v] : hist;
-                double tv = hv[lane * OSTRIDE];
+                const unsigned long long *hv = TEAM ? s_hist[v] : hist;
 #pragma unroll
-                for (int c = 1; c < OCOPIES; c++) tv += hv[lane * OSTRIDE + c];
-                t = v == 0 ? tv : t + tv;
+                for (int c = 0; c < OCOPIES; c++) t += hv[lane * OSTRIDE + c];
             }
-            hsum[lane] = t;
+            hsum[lane] = (double)t * unscale;
         }
         wave_sync();
         if (lane < BINS) {

@@ -192,9 +192,9 @@ def test_batch_schedule_equals_latency_schedule(sift_lib, ctx):
 @pytest.mark.parametrize("name", ["lenna", "lennarotated"])
 def test_all_three_launch_size_tiers_agree_on_the_photographs(ctx, golden, name):
     """The per-keypoint kernels exist in three widths, chosen by the pixels of a launch (up to 1 M, up to 4 M, more):
-    the descriptor tensor is summed in integers, so its three variants agree by construction; the orientation
-    histogram is summed in doubles in a team order and a wave order.  One 512x512 photograph run alone, eight and
-    twenty at a time must give the same keypoints and descriptors, which are the oracle's."""
+    the orientation histogram and the descriptor tensor are summed in integers, so the variants agree by
+    construction.  One 512x512 photograph run alone, eight and twenty at a time must give the same keypoints and
+    descriptors, which are the oracle's."""
     g = golden(name)
     gray = g["gray"]
     h, w = gray.shape
