@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--cpu-knn-seconds", type=float, default=10.0)
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-frames", type=int, default=256)
+    ap.add_argument("--e2e-frames", type=int, default=1024)
     ap.add_argument("--no-configs", action="store_true", help="skip the 3840x2160 and single-frame legs")
     ap.add_argument("--frames-4k", type=int, default=16)
     ap.add_argument("--steps-4k", type=int, default=3)
