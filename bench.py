@@ -355,7 +355,7 @@ def main():
         grp = S.Group(ctxs)
         cg = {"members": members, "devices": devices}
         if not args.no_e2e:
-            nf = members * max(B, args.e2e_frames // B * B)
+            nf = members * max(B, min(args.e2e_frames, 512) // B * B)   # 1 GB of host frames per member
             e2e_host = np.concatenate([host] * ((nf + host.shape[0] - 1) // host.shape[0]))[:nf]
             grp.extract_batch_raw(e2e_host[:members * B], B)       # workspaces, page-locked buffers
             t1 = time.perf_counter()
