@@ -94,7 +94,11 @@ int sift_extract_bgr8(sift_ctx *ctx, const uint8_t *bgr, int w, int h, size_t st
 /* sift_extract_gray8 that also reports the device time of the five stages the reference times with TIMEIT in exec()
  * (sift.cpp:71,72,86,87,92), in milliseconds: gen_gaussian_images, gen_dog_images (always 0: the differences are never
  * stored), gen_scale_space_extrema, clean_keypoints, get_descriptors.  The schedule is that of sift_extract_gray8; the
- * times come from five events at the stage boundaries of the main stream. */
+ * times come from five events at the stage boundaries of the main stream.  Frames of up to 4 M pixels take a schedule
+ * in which blur levels 4-5 of the large octaves run on side streams beside the extrema scans: the boundary between the
+ * first and the third figure is then the end of levels 1-3 of the last octave, i.e. gen_gaussian_images leaves out the
+ * levels 4-5 that are still running and gen_scale_space_extrema takes them in.  Their sum is exact, the split between
+ * the two is approximate; the other boundaries are as the reference's. */
 int sift_extract_gray8_stages(sift_ctx *ctx, const uint8_t *gray, int w, int h, size_t stride, sift_result *out,
                               double stage_ms[5]);
 /* The base image the constructor builds (sift.cpp:40-45): the gray frame upsampled x2 (INTER_LINEAR) and blurred
