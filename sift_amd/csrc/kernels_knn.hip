@@ -227,19 +227,20 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
         // covers.  The branch is taken once per four chains, on the union of their votes.
         v4i acc[QB];
         int mins[QB];
-        unsigned long long votes = 0;
+        unsigned long long vote[QB];
         auto note_min = [&](int qb) {
             int m = min(min(min(acc[qb][0], acc[qb][1]), acc[qb][2]), acc[qb][3]);
             asm volatile("" : "+v"(m));
             mins[qb] = m;
         };
-        auto note_vote = [&](int qb) { votes |= __ballot(mins[qb] < thr[qb]); };
+        // A vote is not read until an MFMA later: a scalar instruction that takes the result of a vector compare
+        // straight away stalls the wave, and with it its next MFMA, until the compare has left the vector pipe.
+        auto note_vote = [&](int qb) { vote[qb] = __ballot(mins[qb] < thr[qb]); };
         auto settle = [&](int q0, int rb) {  // chains q0 .. q0 + 3 of block rb
-            if (votes != 0) {
+            if (((vote[q0] | vote[q0 + 1]) | (vote[q0 + 2] | vote[q0 + 3])) != 0) {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (__any(mins[q0 + k] < thr[q0 + k])) exact_update(acc[q0 + k], q0 + k, rb);
-                votes = 0;
+                    if (vote[q0 + k] != 0) exact_update(acc[q0 + k], q0 + k, rb);
             }
         };
         constexpr int NB = TT / 16;
@@ -270,8 +271,8 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
                 SA_FENCE();
                 if (have) {
                     note_vote(look);
-                    if (qb == 5) settle(0, rb);                 // chains 0..3 of this block
-                    if (qb == 1) settle(4, rb - 1);             // chains 4..7 of the block before, still intact
+                    if (qb == 6) settle(0, rb);                 // chains 0..3 of this block
+                    if (qb == 2 && rb > 0) settle(4, rb - 1);   // chains 4..7 of the block before, still intact
                 }
             }
             SA_FENCE();
