@@ -18,10 +18,13 @@
 // Orientation: train rows are the MFMA rows (A operand, streamed through LDS),
 // queries are the columns (B operand, held in registers for the whole scan), so
 // a lane owns one query of a 16-query block and its 4 accumulator registers are 4 of the
-// block's 16 train rows.  The common case costs a 4-way integer min, one compare and a
-// vote per 16x16 tile: only when some lane's minimum beats its query's current
-// second-best does the tile's accumulator go through the exact update path.  Ties
-// resolve to the smaller train index.
+// block's 16 train rows.  The common case costs a running integer minimum per 16x16 tile and
+// one compare and vote per pair of tiles: only when some lane's minimum beats its query's
+// current second-best do the pair's accumulators go through the exact update path.  Ties
+// resolve to the smaller train index.  The matrix pipe shares the vector issue port and the
+// part's power budget with every other instruction of the wave (each vector instruction per
+// MFMA takes 9-10 % off the rate of a bare MFMA stream, scripts/ubench/mfma_valu_mix.hip), so
+// the loop is built to hold as few of them as it can.
 #include <limits.h>
 
 #include <mutex>
@@ -53,10 +56,15 @@ constexpr int KT = 64 * KW;
 constexpr int QPB = KW * QB * 16;  // queries per workgroup
 constexpr int C_OFF = 126;
 
-// train bias |t|^2 - C*sum(t), one thread per row
-__global__ void k_train_bias(const uint8_t *__restrict__ t, int nt, int *__restrict__ bias) {
+// train bias |t|^2 - C*sum(t), one thread per row.  The array runs on to a whole number of tiles with INT_MAX
+// (such a row can never beat a threshold), followed by 16 zero words that stand in for the bytes of those rows.
+__global__ void k_train_bias(const uint8_t *__restrict__ t, int nt, int *__restrict__ bias, int padded, int *__restrict__ zeros) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nt) return;
+    if (r < 16) zeros[r] = 0;
+    if (r >= nt) {
+        if (r < padded) bias[r] = INT_MAX;
+        return;
+    }
     const uint4 *row = reinterpret_cast<const uint4 *>(t + (size_t)r * 128);
     int sq = 0, sum = 0;
 #pragma unroll
@@ -93,8 +101,10 @@ __device__ __forceinline__ void top2_insert(int s, int idx, int &b1, int &i1, in
 __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
                                                int nt, const int *__restrict__ tbias, int train_base,
                                                int tiles_per_split, sift_knn2 *__restrict__ out) {
-    __shared__ uint4 s_tile[2][TT * 8];
-    __shared__ int s_bias[2][TT];
+    // one array: tiles, then bias words (16-byte pieces)
+    __shared__ uint4 s_all[2 * TT * 8 + 2 * TT / 4];
+    uint4(*s_tile)[TT * 8] = reinterpret_cast<uint4(*)[TT * 8]>(s_all);
+    int(*s_bias)[TT] = reinterpret_cast<int(*)[TT]>(s_all + 2 * TT * 8);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int g = lane >> 4, c = lane & 15;  // k-group / row-group of the lane, column of its query in a block
@@ -145,50 +155,51 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
     const int tile_begin = blockIdx.y * tiles_per_split;
     const int tile_end = min(ntiles, tile_begin + tiles_per_split);
 
+    // A tile goes from memory straight into the LDS (no register staging, no LDS write instructions): one
+    // global_load_lds_dwordx4 of a wave fills 1 KB of consecutive LDS, i.e. 8 rows, so the XOR swizzle of the 16-byte
+    // chunks within a row is applied to the SOURCE address of each lane.  Rows past the end of the train set read the
+    // zero words behind the bias array (their bias is INT_MAX).  Wave 0 also brings the tile's 256 bias words.
+    // The loads are written as inline assembly: for the builtin the compiler assumes the next LDS read may alias the
+    // pending write and waits for the load right after issuing it, which would expose every tile's memory latency.
     constexpr int NST = TT * 8 / KT;  // 16-byte pieces of a tile per thread
-    uint4 stage[NST];
-    int stage_bias = INT_MAX;
-    auto fetch = [&](int tile) {
-#pragma unroll
-        for (int u = 0; u < NST; u++) {
-            const int e = tid + KT * u;
-            const int row = tile * TT + (e >> 3);
-            stage[u] = make_uint4(0, 0, 0, 0);
-            if (row < nt) stage[u] = *reinterpret_cast<const uint4 *>(t + (size_t)row * 128 + (e & 7) * 16);
-        }
-        if (tid < TT) {
-            const int row = tile * TT + tid;
-            stage_bias = row < nt ? tbias[row] : INT_MAX;
-        }
+    using lds_ptr = __attribute__((address_space(3))) void *;
+    auto load_to_lds = [](const void *src, void *wave_base) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_ptr)wave_base);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
     };
-    auto commit = [&](int buf) {
+    const uint8_t *zeros = reinterpret_cast<const uint8_t *>(tbias + ntiles * TT);
+    auto fetch = [&](int tile, int buf) {
 #pragma unroll
         for (int u = 0; u < NST; u++) {
             const int e = tid + KT * u;
-            const int row = e >> 3, chunk = e & 7;
-            s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))] = stage[u];
+            const int row = e >> 3, chunk = (e & 7) ^ ((row >> 1) & 7);
+            const int grow = tile * TT + row;
+            const uint8_t *src = grow < nt ? t + (size_t)grow * 128 + chunk * 16 : zeros;
+            load_to_lds(src, &s_tile[buf][wv * 64 + KT * u]);
         }
-        if (tid < TT) s_bias[buf][tid] = stage_bias;
+        if (wv == 0) load_to_lds(tbias + (size_t)tile * TT + 4 * lane, &s_bias[buf][0]);
     };
 
-    if (tile_begin < tile_end) {
-        fetch(tile_begin);
-        commit(0);
-    }
+    if (tile_begin < tile_end) fetch(tile_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int tile = tile_begin; tile < tile_end; tile++) {
         const int buf = (tile - tile_begin) & 1;
-        if (tile + 1 < tile_end) fetch(tile + 1);
+        if (tile + 1 < tile_end) fetch(tile + 1, buf ^ 1);
         // Pass over the tile, 16 train rows at a time.  A block of rows is eight chains of two MFMAs, one chain
         // per 16-query block; a chain's accumulator (this lane's four rows of its query) goes through the exact
         // update only when some lane's minimum beats that lane's threshold (a wave-uniform branch, rarely taken
         // once the thresholds have tightened), while it is still live.
         //
         // The pass is software-pipelined by hand, one scheduling fence per MFMA: behind the first MFMA of a
-        // chain the wave issues one LDS read of the next block's operands (first three chains), behind the
-        // second the minimum of the chain before (two vector instructions, a compare and a vote), whose
-        // result has left the matrix pipe by then.
+        // chain the wave issues the minimum of the chain two before it (two vector instructions), whose result
+        // has left the matrix pipe by then, and one LDS read of the next block's operands (three of the chains);
+        // behind the second MFMA the compare and the vote, for the chains of odd row blocks.
         auto load_af = [&](int rb, int ks, v4i &dst) {
             const int row = rb * 16 + c, chunk = ks * 4 + g;
             const uint4 a = s_tile[buf][row * 8 + (chunk ^ ((row >> 1) & 7))];
@@ -221,30 +232,36 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
             const int u1 = __shfl_xor(t1, 32), u2 = __shfl_xor(t2, 32);
             thr[qb] = min(max(t1, u1), min(t2, u2));
         };
-        // A chain is looked at two chains later, when its result has long left the matrix pipe: its minimum
-        // (two vector instructions, pinned where they are written) behind the first MFMA of that chain, the
-        // compare and the vote behind the second, so that neither gap holds more than the MFMA beside it
-        // covers.  The branch is taken once per four chains, on the union of their votes.
-        v4i acc[QB];
+        // A chain is looked at two chains later, when its result has long left the matrix pipe.  The branch to the
+        // exact update is taken once per four chains and pair of row blocks, on the union of their votes.
+        // Row blocks are looked at in pairs: the even block's minimum is only kept (two vector instructions), the odd
+        // block's is folded into it (two) and compared with the threshold (one), so a pair costs five instead of six
+        // and half the scalar work; both accumulators of a pair stay live until the pair has been settled.
+        v4i acc[2][QB];
         int mins[QB];
         unsigned long long vote[QB];
-        auto note_min = [&](int qb) {
-            int m = min(min(min(acc[qb][0], acc[qb][1]), acc[qb][2]), acc[qb][3]);
+        auto note_min = [&](int qb, int par) {
+            int m;
+            if (par == 0) m = min(min(min(acc[0][qb][0], acc[0][qb][1]), acc[0][qb][2]), acc[0][qb][3]);
+            else m = min(min(min(min(mins[qb], acc[1][qb][0]), acc[1][qb][1]), acc[1][qb][2]), acc[1][qb][3]);
             asm volatile("" : "+v"(m));
             mins[qb] = m;
         };
         // A vote is not read until an MFMA later: a scalar instruction that takes the result of a vector compare
         // straight away stalls the wave, and with it its next MFMA, until the compare has left the vector pipe.
         auto note_vote = [&](int qb) { vote[qb] = __ballot(mins[qb] < thr[qb]); };
-        auto settle = [&](int q0, int rb) {  // chains q0 .. q0 + 3 of block rb
+        auto settle = [&](int q0, int rb) {  // chains q0 .. q0 + 3 of blocks rb - 1 and rb (rb odd)
             if (((vote[q0] | vote[q0 + 1]) | (vote[q0 + 2] | vote[q0 + 3])) != 0) {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (vote[q0 + k] != 0) exact_update(acc[q0 + k], q0 + k, rb);
+                    if (vote[q0 + k] != 0) {
+                        exact_update(acc[0][q0 + k], q0 + k, rb - 1);
+                        exact_update(acc[1][q0 + k], q0 + k, rb);
+                    }
             }
         };
         constexpr int NB = TT / 16;
-        static_assert(QB == 8, "the schedule below settles the chains in two groups of four");
+        static_assert(QB == 8 && NB % 2 == 0, "the schedule below settles the chains in two groups of four, row blocks in pairs");
         v4i af[2], afn[2], cinit, cinitn;
         load_af(0, 0, af[0]);
         load_af(0, 1, af[1]);
@@ -253,26 +270,28 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
 #pragma unroll
         for (int rb = 0; rb < NB; rb++) {
             const bool more = rb + 1 < NB;
+            const int par = rb & 1;
 #pragma unroll
             for (int qb = 0; qb < QB; qb++) {
                 const int look = (qb + QB - 2) % QB;            // the chain two back: 6, 7 of the block before, then 0..5
+                const int look_par = qb >= 2 ? par : par ^ 1;   // parity of the row block that chain belongs to
                 const bool have = qb >= 2 || rb > 0;
                 SA_FENCE();
-                acc[qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[qb][0], cinit, 0, 0, 0);
+                acc[par][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[qb][0], cinit, 0, 0, 0);
                 SA_FENCE();
-                if (have) note_min(look);
+                if (have) note_min(look, look_par);
                 if (more) {
                     if (qb == 2) load_af(rb + 1, 0, afn[0]);
                     if (qb == 3) load_af(rb + 1, 1, afn[1]);
                     if (qb == 4) load_bias(rb + 1, cinitn);
                 }
                 SA_FENCE();
-                acc[qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[qb][1], acc[qb], 0, 0, 0);
+                acc[par][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[qb][1], acc[par][qb], 0, 0, 0);
                 SA_FENCE();
                 if (have) {
-                    note_vote(look);
-                    if (qb == 6) settle(0, rb);                 // chains 0..3 of this block
-                    if (qb == 2 && rb > 0) settle(4, rb - 1);   // chains 4..7 of the block before, still intact
+                    if (look_par == 1) note_vote(look);
+                    if (qb == 6 && par == 1) settle(0, rb);                 // chains 0..3 of this pair
+                    if (qb == 2 && par == 0 && rb > 0) settle(4, rb - 1);   // chains 4..7 of the pair before, still intact
                 }
             }
             SA_FENCE();
@@ -282,14 +301,14 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
                 cinit = cinitn;
             }
         }
-        note_min(QB - 2);
+        note_min(QB - 2, 1);
         note_vote(QB - 2);
-        note_min(QB - 1);
+        note_min(QB - 1, 1);
         note_vote(QB - 1);
         settle(4, NB - 1);
         SA_FENCE();
 #undef SA_FENCE
-        if (tile + 1 < tile_end) commit(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads into the other buffer have landed
         __syncthreads();
     }
 
@@ -367,21 +386,27 @@ hipError_t knn_static_scratch(int device, void **ptr) {
 
 // Train biases, then one partial result row per train split (none when the launch has a single split:
 // it writes the caller's output directly).
+static size_t bias_block_bytes(int nt) {  // bias words of whole tiles + the zero words, rounded to 256 bytes
+    const size_t padded = (size_t)((nt + TT - 1) / TT) * TT;
+    return ((padded + 16) * sizeof(int) + 255) & ~(size_t)255;
+}
+
 size_t knn_scratch_bytes(int nq, int nt) {
     const int splits = choose_splits(nq, nt);
-    size_t bias = ((size_t)nt * sizeof(int) + 255) & ~(size_t)255;
-    return bias + (splits > 1 ? (size_t)splits * nq * sizeof(sift_knn2) : 0);
+    return bias_block_bytes(nt) + (splits > 1 ? (size_t)splits * nq * sizeof(sift_knn2) : 0);
 }
 
 void launch_knn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int train_base, sift_knn2 *out,
                  void *scratch) {
     if (nq <= 0) return;
     int *bias = reinterpret_cast<int *>(scratch);
-    const size_t bias_bytes = ((size_t)nt * sizeof(int) + 255) & ~(size_t)255;
+    const size_t bias_bytes = bias_block_bytes(nt);
     sift_knn2 *parts = reinterpret_cast<sift_knn2 *>(reinterpret_cast<char *>(scratch) + bias_bytes);
-    if (nt > 0) hipLaunchKernelGGL(k_train_bias, dim3((nt + 255) / 256), dim3(256), 0, st, t, nt, bias);
-    const int splits = choose_splits(nq, nt);
     const int ntiles = (nt + TT - 1) / TT;
+    if (nt > 0)
+        hipLaunchKernelGGL(k_train_bias, dim3(ntiles * TT / 256), dim3(256), 0, st, t, nt, bias, ntiles * TT,
+                           bias + ntiles * TT);
+    const int splits = choose_splits(nq, nt);
     const int tps = splits > 0 && ntiles > 0 ? (ntiles + splits - 1) / splits : 1;
     const int qblocks = (nq + QPB - 1) / QPB;
     if (splits == 1) {
