@@ -163,25 +163,39 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
     // pending write and waits for the load right after issuing it, which would expose every tile's memory latency.
     constexpr int NST = TT * 8 / KT;  // 16-byte pieces of a tile per thread
     using lds_ptr = __attribute__((address_space(3))) void *;
-    auto load_to_lds = [](const void *src, void *wave_base) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_ptr)wave_base);
+    auto load_to_lds = [](const void *src, unsigned dst) {  // dst: LDS byte address of the wave's 1 KB, wave-uniform
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(src), "s"(dst)
                      : "memory");
     };
+    const unsigned lds_tiles = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_ptr)&s_tile[0][wv * 64]);
+    const unsigned lds_bias = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_ptr)&s_bias[0][0]);
     const uint8_t *zeros = reinterpret_cast<const uint8_t *>(tbias + ntiles * TT);
-    auto fetch = [&](int tile, int buf) {
+    // source of each of this thread's pieces in the next tile to fetch; they move on by one tile per fetch
+    const uint8_t *piece[NST];
 #pragma unroll
-        for (int u = 0; u < NST; u++) {
-            const int e = tid + KT * u;
-            const int row = e >> 3, chunk = (e & 7) ^ ((row >> 1) & 7);
-            const int grow = tile * TT + row;
-            const uint8_t *src = grow < nt ? t + (size_t)grow * 128 + chunk * 16 : zeros;
-            load_to_lds(src, &s_tile[buf][wv * 64 + KT * u]);
+    for (int u = 0; u < NST; u++) {
+        const int e = tid + KT * u;
+        const int row = e >> 3, chunk = (e & 7) ^ ((row >> 1) & 7);
+        piece[u] = t + ((size_t)tile_begin * TT + row) * 128 + chunk * 16;
+    }
+    const int *bias_piece = tbias + (size_t)tile_begin * TT + 4 * lane;
+    auto fetch = [&](int tile, int buf) {
+        const unsigned dst = lds_tiles + buf * (unsigned)(TT * 128);
+        if (tile == ntiles - 1 && (nt & (TT - 1)) != 0) {  // only the train set's last tile can hold rows past its end
+#pragma unroll
+            for (int u = 0; u < NST; u++)
+                load_to_lds(tile * TT + ((tid + KT * u) >> 3) < nt ? piece[u] : zeros, dst + u * (KT * 16));
+        } else {
+#pragma unroll
+            for (int u = 0; u < NST; u++) load_to_lds(piece[u], dst + u * (KT * 16));
         }
-        if (wv == 0) load_to_lds(tbias + (size_t)tile * TT + 4 * lane, &s_bias[buf][0]);
+#pragma unroll
+        for (int u = 0; u < NST; u++) piece[u] += TT * 128;
+        if (wv == 0) load_to_lds(bias_piece, lds_bias + buf * (unsigned)(TT * 4));
+        bias_piece += TT;
     };
 
     if (tile_begin < tile_end) fetch(tile_begin, 0);
