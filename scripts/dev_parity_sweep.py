@@ -11,6 +11,9 @@ BIG = os.environ.get('SWEEP') == 'big'
 CASES = [(1920, 1080, 1, 6), (960, 540, 1, 6), (640, 480, 9, 8)]
 if BIG:
     CASES = [(1920, 1080, 3, 24), (1280, 720, 4, 24), (640, 480, 5, 40), (1001, 703, 6, 12), (3840, 2160, 7, 2), (333, 517, 8, 20)]
+if os.environ.get('SWEEP') == 'big2':  # other seeds and sizes than 'big'
+    CASES = [(1920, 1080, 11, 24), (1280, 720, 12, 24), (800, 600, 13, 30), (1023, 767, 14, 12), (3840, 2160, 15, 2),
+             (517, 333, 16, 20), (2048, 1080, 2, 4), (1366, 768, 17, 12)]
 for (w, h, seed, nf) in CASES:
     b = ctx.batch(w, h, 1)
     for f in range(nf):
