@@ -97,6 +97,32 @@ def test_ragged_sizes(sift_lib, ctx, oracle, w, h, seed):
     run_both(sift_lib, ctx, oracle, sift_lib.synth_dead_leaves(seed, 0, w, h))
 
 
+def _texture(kind, seed, w, h):
+    """Frames that are not piecewise constant (the dead-leaves generator's are): every pixel has a gradient, so the
+    arctangent, the square root and the histogram votes see generic operands."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w)).astype(np.uint8)
+    if kind == "lowpass":
+        k = 5
+        up = np.kron(rng.integers(0, 256, (h // k + 2, w // k + 2)).astype(np.float64), np.ones((k, k)))[:h + k, :w + k]
+        c = np.cumsum(np.cumsum(np.pad(up, ((1, 0), (1, 0))), 0), 1)  # k x k box filter by summed-area table
+        box = (c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]) / (k * k)
+        return np.clip(np.rint(box[:h, :w] + rng.normal(0, 2, (h, w))), 0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    acc = np.zeros((h, w))
+    for _ in range(12):
+        th, fr, ph, am = rng.uniform(0, np.pi), rng.uniform(0.01, 0.25), rng.uniform(0, 6.28), rng.uniform(5, 30)
+        acc += am * np.sin(fr * (np.cos(th) * xx + np.sin(th) * yy) + ph)
+    return np.clip(np.rint(128 + acc), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind,w,h,seed", [("noise", 200, 150, 51), ("lowpass", 400, 300, 52), ("waves", 333, 517, 53)])
+def test_textured_frames(sift_lib, ctx, oracle, kind, w, h, seed):
+    """White noise, low-pass noise and sums of oriented sinusoids against the oracle, pyramid levels included."""
+    run_both(sift_lib, ctx, oracle, _texture(kind, seed, w, h))
+
+
 @pytest.mark.parametrize("w,h,seed", [(2, 2, 31), (3, 7, 32), (8, 8, 33), (5, 300, 34), (300, 5, 35), (2, 64, 36), (17, 2, 37),
                                       (40, 23, 38)])
 def test_tiny_and_sliver_frames(sift_lib, ctx, oracle, w, h, seed):
