@@ -265,13 +265,21 @@ __global__ __launch_bounds__(KT, 2) void k_knn2(const uint8_t *__restrict__ q, i
         // straight away stalls the wave, and with it its next MFMA, until the compare has left the vector pipe.
         auto note_vote = [&](int qb) { vote[qb] = __ballot(mins[qb] < thr[qb]); };
         auto settle = [&](int q0, int rb) {  // chains q0 .. q0 + 3 of blocks rb - 1 and rb (rb odd)
-            if (((vote[q0] | vote[q0 + 1]) | (vote[q0 + 2] | vote[q0 + 3])) != 0) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (vote[q0 + k] != 0) {
-                        exact_update(acc[0][q0 + k], q0 + k, rb - 1);
-                        exact_update(acc[1][q0 + k], q0 + k, rb);
+            // Marked unlikely, the update code is laid out behind the loop and the common path falls through instead
+            // of jumping over it after every group.  The four chains are written out: in code the compiler takes for
+            // cold it does not unroll a loop over them, and an accumulator array indexed by a loop variable lives
+            // in scratch memory.
+            if (__builtin_expect(((vote[q0] | vote[q0 + 1]) | (vote[q0 + 2] | vote[q0 + 3])) != 0, 0)) {
+                auto one = [&](int qq) {
+                    if (vote[qq] != 0) {
+                        exact_update(acc[0][qq], qq, rb - 1);
+                        exact_update(acc[1][qq], qq, rb);
                     }
+                };
+                one(q0);
+                one(q0 + 1);
+                one(q0 + 2);
+                one(q0 + 3);
             }
         };
         constexpr int NB = TT / 16;
