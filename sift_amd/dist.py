@@ -33,12 +33,8 @@ def _hip_local_knn(ctx):
 
     def run(q, t, train_base):
         out = torch.empty((q.shape[0], 4), dtype=torch.int32, device=q.device)
-        # q and t may have been produced by torch work that is still in flight on torch's stream (a cast, a slice, a
-        # receive), and the context launches on a stream of its own
-        torch.cuda.current_stream().synchronize()
         ctx.knn2_device(q.data_ptr(), q.shape[0], t.data_ptr() if t.shape[0] else 0, t.shape[0], train_base,
                         out.data_ptr())
-        ctx.synchronize()
         return out
     return run
 
@@ -50,11 +46,64 @@ def _hip_merge(ctx):
         nparts, n, _ = parts.shape
         out = torch.empty((n, 4), dtype=torch.int32, device=parts.device)
         acc = torch.empty((n,), dtype=torch.uint8, device=parts.device)
-        torch.cuda.current_stream().synchronize()
         ctx.knn2_merge_device(parts.data_ptr(), nparts, n, out.data_ptr(), acc.data_ptr())
-        ctx.synchronize()
         return out, acc
     return run
+
+
+def _synchronised(ctx, fn):
+    """The host-synchronised form, for a HIP kernel used beside an injected stand-in: torch's stream is drained
+    before the engine's stream starts and the engine's before torch goes on."""
+    import torch
+
+    def run(*args):
+        torch.cuda.current_stream().synchronize()
+        out = fn(*args)
+        ctx.synchronize()
+        return out
+    return run
+
+
+class _on_engine_stream:
+    """Runs a block of torch work on the context's own HIP stream: the engine's kernels, the tensors torch fills
+    around them and the collectives are then ordered by that one stream, with no host synchronisation.  On entry the
+    engine stream waits for the caller's stream (the inputs may still be in flight there); on exit the caller's stream
+    waits for the engine stream, and the tensors handed back are marked as in use on the caller's stream."""
+
+    def __init__(self, ctx):
+        import torch
+        self.torch = torch
+        self.engine = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", ctx.device))
+        self.caller = None
+        self.guard = None
+
+    def __enter__(self):
+        self.caller = self.torch.cuda.current_stream(self.engine.device)
+        self.engine.wait_stream(self.caller)
+        self.guard = self.torch.cuda.stream(self.engine)
+        self.guard.__enter__()
+        return self
+
+    def hand_back(self, *tensors):
+        for t in tensors:
+            t.record_stream(self.caller)
+        return tensors
+
+    def __exit__(self, *exc):
+        self.guard.__exit__(*exc)
+        self.caller.wait_stream(self.engine)
+        return False
+
+
+class _no_stream:
+    def __enter__(self):
+        return self
+
+    def hand_back(self, *tensors):
+        return tensors
+
+    def __exit__(self, *exc):
+        return False
 
 
 def sharded_knn2(q, t_shard, train_base, *, ctx=None, group=None, local_knn=None, merge=None, gather=True):
@@ -74,27 +123,36 @@ def sharded_knn2(q, t_shard, train_base, *, ctx=None, group=None, local_knn=None
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    # with the HIP kernels everything below runs on the engine's stream; injected stand-ins run wherever they like
+    scope = _on_engine_stream(ctx) if (local_knn is None and merge is None and ctx is not None) else _no_stream()
     if local_knn is None:
         local_knn = _hip_local_knn(ctx)
+        if not isinstance(scope, _on_engine_stream):
+            local_knn = _synchronised(ctx, local_knn)
     if merge is None:
         merge = _hip_merge(ctx)
+        if not isinstance(scope, _on_engine_stream):
+            merge = _synchronised(ctx, merge)
     nq = q.shape[0]
-    part = local_knn(q, t_shard, train_base)                       # [nq, 4]
-    slice_len = (nq + world - 1) // world                          # equal slices, last one padded
-    padded = torch.full((world * slice_len, 4), -1, dtype=torch.int32, device=part.device)
-    padded[:, 0] = np.iinfo(np.int32).max
-    padded[:, 2] = np.iinfo(np.int32).max
-    padded[:nq] = part
-    recv = torch.empty_like(padded)
-    # slice s of every rank's partial result goes to rank s: 16 bytes per query per peer
-    dist.all_to_all_single(recv, padded, group=group)
-    merged, accept = merge(recv.view(world, slice_len, 4).contiguous())
-    lo, hi = rank * slice_len, min(nq, (rank + 1) * slice_len)
-    if not gather:
-        n = max(0, hi - lo)
-        return merged[:n], accept[:n], (lo, hi)
-    all_m = torch.empty((world * slice_len, 4), dtype=torch.int32, device=merged.device)
-    all_a = torch.empty((world * slice_len,), dtype=torch.uint8, device=merged.device)
-    dist.all_gather_into_tensor(all_m, merged.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_a, accept.contiguous(), group=group)
-    return all_m[:nq], all_a[:nq], (0, nq)
+    with scope:
+        part = local_knn(q, t_shard, train_base)                       # [nq, 4]
+        slice_len = (nq + world - 1) // world                          # equal slices, last one padded
+        padded = torch.full((world * slice_len, 4), -1, dtype=torch.int32, device=part.device)
+        padded[:, 0] = np.iinfo(np.int32).max
+        padded[:, 2] = np.iinfo(np.int32).max
+        padded[:nq] = part
+        recv = torch.empty_like(padded)
+        # slice s of every rank's partial result goes to rank s: 16 bytes per query per peer
+        dist.all_to_all_single(recv, padded, group=group)
+        merged, accept = merge(recv.view(world, slice_len, 4).contiguous())
+        lo, hi = rank * slice_len, min(nq, (rank + 1) * slice_len)
+        if not gather:
+            n = max(0, hi - lo)
+            merged, accept = scope.hand_back(merged[:n], accept[:n])
+            return merged, accept, (lo, hi)
+        all_m = torch.empty((world * slice_len, 4), dtype=torch.int32, device=merged.device)
+        all_a = torch.empty((world * slice_len,), dtype=torch.uint8, device=merged.device)
+        dist.all_gather_into_tensor(all_m, merged.contiguous(), group=group)
+        dist.all_gather_into_tensor(all_a, accept.contiguous(), group=group)
+        all_m, all_a = scope.hand_back(all_m[:nq], all_a[:nq])
+        return all_m, all_a, (0, nq)
