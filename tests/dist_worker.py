@@ -40,8 +40,36 @@ def merge(parts):
     return torch.from_numpy(out), torch.from_numpy(acc)
 
 
+def hip_kernels():
+    """The two HIP kernels of GPU 0 behind CPU tensors (every rank of the test shares the one GPU; the exchange itself
+    stays on gloo)."""
+    ctx = sift_amd.Context(0)
+
+    def search(q, t, base):
+        dq, dt = q.cuda(), t.cuda()
+        out = torch.empty((q.shape[0], 4), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.knn2_device(dq.data_ptr(), q.shape[0], dt.data_ptr() if t.shape[0] else 0, t.shape[0], base, out.data_ptr())
+        ctx.synchronize()
+        return out.cpu()
+
+    def merge_parts(parts):
+        dp = parts.contiguous().cuda()
+        nparts, n, _ = parts.shape
+        out = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+        acc = torch.empty((n,), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.knn2_merge_device(dp.data_ptr(), nparts, n, out.data_ptr(), acc.data_ptr())
+        ctx.synchronize()
+        return out.cpu(), acc.cpu()
+    return search, merge_parts
+
+
 def main():
+    global local_knn, merge
     outdir, nq, nt = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    if len(sys.argv) > 4 and sys.argv[4] == "hip":
+        local_knn, merge = hip_kernels()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     train = sift_amd.synth_descriptors(5, nt)

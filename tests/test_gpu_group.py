@@ -212,3 +212,35 @@ def test_sharded_knn2_over_a_one_rank_rccl_group(sift_lib, ctx, oracle):
     finally:
         if started:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,port", [(2, 29651), (3, 29652)])
+def test_sharded_matcher_over_several_processes_with_the_hip_kernels(sift_lib, oracle, tmp_path, world, port):
+    """Two and three ranks (separate processes that share this box's GPU): each rank's HIP search over its train shard
+    with global indices, the exchange of query slices (gloo here: RCCL takes one rank per GPU), the HIP merge on each
+    slice owner.  Equal to the unsharded CPU brute force whatever the number of ranks; the query count does not divide
+    by it and the last train shard is ragged."""
+    import os
+    import subprocess
+    import sys
+    nq, nt = 1001, 30011
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dist_worker.py"),
+           str(tmp_path), str(nq), str(nt), "hip"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    train = sift_lib.synth_descriptors(5, nt)
+    queries = sift_lib.synth_queries(6, train, nq)
+    i1, d1, i2, d2, acc = oracle.knn2_u8(queries, train, threads=16)
+    slice_len = (nq + world - 1) // world
+    for r in range(world):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        k = z["knn"]
+        assert np.array_equal(k[:, 0], d1) and np.array_equal(k[:, 1], i1)
+        assert np.array_equal(k[:, 2], d2) and np.array_equal(k[:, 3], i2)
+        assert np.array_equal(z["acc"], acc)
+        lo, hi = z["span_slice"]
+        assert (lo, hi) == (r * slice_len, min(nq, (r + 1) * slice_len))
+        assert np.array_equal(z["knn_slice"][:, 1], i1[lo:hi]) and np.array_equal(z["acc_slice"], acc[lo:hi])
