@@ -258,12 +258,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the several-rank flow on a box with one GPU (RCCL takes one rank per device): every rank on GPU 0
+    # and the process group on gloo.  SIFT_BENCH_REHEARSAL=1 torchrun ... bench.py --gpus N --no-knn --batch 8
+    rehearsal = os.environ.get("SIFT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -333,7 +341,7 @@ def main():
         torch.cuda.synchronize(d)
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kp_mean = float(np.mean([bt.counts(Bs)["keypoints"].mean() for bt in batches]))
@@ -391,7 +399,7 @@ def main():
 
     # ---- sharded matcher: every rank holds knn_train rows of the train set and all queries;
     # local top-2, one all-to-all of 16 B per query per peer, merge on the owner of each slice
-    if (world > 1 or args.force_sharded_knn) and not args.no_knn:
+    if (world > 1 or args.force_sharded_knn) and not args.no_knn and not rehearsal:  # gloo has no GPU all-to-all
         if dist is None:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
